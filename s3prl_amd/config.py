@@ -1,0 +1,172 @@
+"""Typed view of the hyper-parameters that select kernel variants on the upstream-encoder path.
+
+Mirrors the subset of the reference config objects that the forward actually reads:
+
+* ``HubertConfig`` / ``HubertPretrainingConfig``  (s3prl/upstream/hubert/hubert_model.py:33-278)
+* ``Wav2Vec2Config`` / ``AudioPretrainingConfig`` (s3prl/upstream/wav2vec2/wav2vec2_model.py:2103-2350,3325-3345)
+* ``WavLMConfig``                                 (s3prl/upstream/wavlm/WavLM.py:162-245)
+
+Like ``merge_with_parent`` (s3prl/upstream/utils.py:31-44) unknown keys of a checkpoint's
+config dict are dropped, missing ones fall back to the reference defaults.
+"""
+
+from __future__ import annotations
+
+import ast
+from dataclasses import dataclass, field, asdict
+from typing import Dict, List, Tuple
+
+FAMILIES = ("hubert", "wav2vec2", "wavlm")
+
+# reference default: "[(512,10,5)] + [(512,3,2)] * 4 + [(512,2,2)] * 2"
+DEFAULT_CONV_LAYERS = "[(512,10,5)] + [(512,3,2)] * 4 + [(512,2,2)] * 2"
+
+
+def parse_conv_layers(spec) -> List[Tuple[int, int, int]]:
+    """The reference ``eval``s this string (hubert_model.py:297, wav2vec2_model.py:2357).
+
+    We only accept the arithmetic-on-literal-lists subset, evaluated without ``eval``.
+    """
+    if not isinstance(spec, str):
+        return [tuple(int(v) for v in t) for t in spec]
+
+    def ev(node):
+        if isinstance(node, ast.Expression):
+            return ev(node.body)
+        if isinstance(node, ast.BinOp) and isinstance(node.op, ast.Add):
+            return ev(node.left) + ev(node.right)
+        if isinstance(node, ast.BinOp) and isinstance(node.op, ast.Mult):
+            l, r = ev(node.left), ev(node.right)
+            return l * r
+        if isinstance(node, (ast.List, ast.Tuple)):
+            vals = [ev(e) for e in node.elts]
+            return vals if isinstance(node, ast.List) else tuple(vals)
+        if isinstance(node, ast.Constant) and isinstance(node.value, int):
+            return node.value
+        raise ValueError(f"unsupported conv_feature_layers expression: {spec!r}")
+
+    layers = ev(ast.parse(spec, mode="eval"))
+    out = []
+    for t in layers:
+        if len(t) != 3:
+            raise ValueError("invalid conv definition: " + str(t))
+        out.append((int(t[0]), int(t[1]), int(t[2])))
+    return out
+
+
+@dataclass
+class EncoderConfig:
+    family: str = "hubert"
+    conv_layers: List[Tuple[int, int, int]] = field(
+        default_factory=lambda: parse_conv_layers(DEFAULT_CONV_LAYERS)
+    )
+    extractor_mode: str = "default"  # "default" (GroupNorm after conv0) | "layer_norm"
+    conv_bias: bool = False
+    encoder_layers: int = 12
+    encoder_embed_dim: int = 768
+    encoder_ffn_embed_dim: int = 3072
+    encoder_attention_heads: int = 12
+    layer_norm_first: bool = False
+    conv_pos: int = 128
+    conv_pos_groups: int = 16
+    normalize: bool = False  # task_cfg.normalize: per-utterance waveform layer-norm
+    # WavLM only
+    relative_position_embedding: bool = False
+    num_buckets: int = 320
+    max_distance: int = 1280
+    gru_rel_pos: bool = False
+
+    # ---- derived -------------------------------------------------------------------------
+    @property
+    def conv_dim(self) -> int:
+        return self.conv_layers[-1][0]
+
+    @property
+    def head_dim(self) -> int:
+        return self.encoder_embed_dim // self.encoder_attention_heads
+
+    @property
+    def downsample_rate(self) -> int:
+        r = 1
+        for _, _, s in self.conv_layers:
+            r *= s
+        return r
+
+    def conv_lengths(self, n: int) -> List[int]:
+        """floor((L-k)/s)+1 per layer (wav2vec2_model.py:2615-2616)."""
+        out = []
+        for _, k, s in self.conv_layers:
+            n = (n - k) // s + 1 if n >= k else 0
+            out.append(n)
+        return out
+
+    def num_frames(self, n: int) -> int:
+        return self.conv_lengths(n)[-1]
+
+    def valid_frames(self, length: int, n_max: int) -> int:
+        """Number of un-masked frames of an utterance of ``length`` samples in a batch padded to
+        ``n_max`` samples.
+
+        hubert / wavlm: ``forward_padding_mask`` (hubert_model.py:454-464, WavLM.py:339-349):
+        chunk = n_max // T; frame t is padding iff all samples of its chunk are padding.
+        wav2vec2: conv-length formula of ``length`` (wav2vec2_model.py:2652-2669).
+        """
+        T = self.num_frames(n_max)
+        if T <= 0:
+            return 0
+        if self.family == "wav2vec2":
+            return min(T, max(self.num_frames(length), 0))
+        chunk = n_max // T
+        return min(T, -(-length // chunk))
+
+    def validate(self) -> None:
+        if self.family not in FAMILIES:
+            raise ValueError(f"unknown family {self.family!r}")
+        if self.extractor_mode not in ("default", "layer_norm"):
+            raise ValueError(f"unknown extractor_mode {self.extractor_mode!r}")
+        dims = {d for d, _, _ in self.conv_layers}
+        if len(dims) != 1:
+            raise ValueError("all conv feature layers must have the same width")
+        if self.encoder_embed_dim % self.encoder_attention_heads:
+            raise ValueError("embed_dim must be divisible by num_heads")
+        if self.head_dim != 64:
+            raise ValueError("the HIP attention kernel is specialised for head_dim == 64")
+        if self.encoder_embed_dim % self.conv_pos_groups:
+            raise ValueError("embed_dim must be divisible by conv_pos_groups")
+
+    def to_dict(self) -> Dict:
+        return asdict(self)
+
+
+_MODEL_KEYS = (
+    "extractor_mode", "conv_bias", "encoder_layers", "encoder_embed_dim", "encoder_ffn_embed_dim",
+    "encoder_attention_heads", "layer_norm_first", "conv_pos", "conv_pos_groups",
+)
+_WAVLM_KEYS = ("relative_position_embedding", "num_buckets", "max_distance", "gru_rel_pos", "normalize")
+
+
+def config_from_dicts(family: str, model_cfg: Dict, task_cfg: Dict | None = None) -> EncoderConfig:
+    """Build an :class:`EncoderConfig` from the dicts stored in a converted checkpoint (§3.4)."""
+    cfg = EncoderConfig(family=family)
+    for k in _MODEL_KEYS:
+        if k in model_cfg and model_cfg[k] is not None:
+            setattr(cfg, k, type(getattr(cfg, k))(model_cfg[k]))
+    if "conv_feature_layers" in model_cfg:
+        cfg.conv_layers = parse_conv_layers(model_cfg["conv_feature_layers"])
+    act = model_cfg.get("activation_fn", "gelu")
+    act = getattr(act, "name", act)
+    if str(act) != "gelu":
+        raise ValueError(f"only activation_fn='gelu' is on the hot path, got {act!r}")
+    if str(model_cfg.get("layer_type", "transformer")).endswith("conformer"):
+        raise ValueError("conformer layers are out of scope (SURVEY §2.1)")
+    if int(model_cfg.get("pos_conv_depth", 1)) != 1:
+        raise ValueError("pos_conv_depth > 1 (data2vec) is out of scope (SURVEY §8f)")
+    if family == "wavlm":
+        for k in _WAVLM_KEYS:
+            if k in model_cfg:
+                setattr(cfg, k, type(getattr(cfg, k))(model_cfg[k]))
+    else:
+        if task_cfg is not None and "normalize" in task_cfg:
+            cfg.normalize = bool(task_cfg["normalize"])
+    cfg.validate()
+    return cfg

@@ -1,0 +1,161 @@
+"""Deterministic synthetic checkpoints and waveforms.
+
+There is no network for real checkpoints, so benchmarks, tests and the golden
+fixtures all use weights drawn from a seeded numpy generator, named exactly like the reference
+``state_dict`` entries on the hot path, so that the very same tensors can be loaded
+into the reference classes (``tests/golden/make_golden.py``) and into the HIP encoder.
+
+The scales are chosen so activations stay O(1) through 12-24 layers and so that every bias /
+affine parameter is exercised (none is left at its 0/1 default).
+"""
+
+from __future__ import annotations
+
+from typing import Dict, List
+
+import numpy as np
+
+from .config import EncoderConfig
+
+
+def param_shapes(cfg: EncoderConfig) -> Dict[str, tuple]:
+    """Hot-path parameter names → shapes (reference naming)."""
+    s: Dict[str, tuple] = {}
+    cin = 1
+    for i, (dim, k, _) in enumerate(cfg.conv_layers):
+        p = f"feature_extractor.conv_layers.{i}"
+        s[f"{p}.0.weight"] = (dim, cin, k)
+        if cfg.conv_bias:
+            s[f"{p}.0.bias"] = (dim,)
+        if cfg.extractor_mode == "layer_norm":
+            s[f"{p}.2.1.weight"] = (dim,)
+            s[f"{p}.2.1.bias"] = (dim,)
+        elif i == 0:
+            s[f"{p}.2.weight"] = (dim,)
+            s[f"{p}.2.bias"] = (dim,)
+        cin = dim
+    C, D, F, H = cfg.conv_dim, cfg.encoder_embed_dim, cfg.encoder_ffn_embed_dim, cfg.encoder_attention_heads
+    s["layer_norm.weight"] = (C,)
+    s["layer_norm.bias"] = (C,)
+    s["post_extract_proj.weight"] = (D, C)
+    s["post_extract_proj.bias"] = (D,)
+    s["encoder.pos_conv.0.bias"] = (D,)
+    s["encoder.pos_conv.0.weight_g"] = (1, 1, cfg.conv_pos)
+    s["encoder.pos_conv.0.weight_v"] = (D, D // cfg.conv_pos_groups, cfg.conv_pos)
+    s["encoder.layer_norm.weight"] = (D,)
+    s["encoder.layer_norm.bias"] = (D,)
+    for l in range(cfg.encoder_layers):
+        p = f"encoder.layers.{l}"
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            s[f"{p}.self_attn.{n}.weight"] = (D, D)
+            s[f"{p}.self_attn.{n}.bias"] = (D,)
+        s[f"{p}.self_attn_layer_norm.weight"] = (D,)
+        s[f"{p}.self_attn_layer_norm.bias"] = (D,)
+        s[f"{p}.fc1.weight"] = (F, D)
+        s[f"{p}.fc1.bias"] = (F,)
+        s[f"{p}.fc2.weight"] = (D, F)
+        s[f"{p}.fc2.bias"] = (D,)
+        s[f"{p}.final_layer_norm.weight"] = (D,)
+        s[f"{p}.final_layer_norm.bias"] = (D,)
+        if cfg.family == "wavlm":
+            if cfg.relative_position_embedding and l == 0:
+                s[f"{p}.self_attn.relative_attention_bias.weight"] = (cfg.num_buckets, H)
+            if cfg.gru_rel_pos:
+                s[f"{p}.self_attn.grep_linear.weight"] = (8, cfg.head_dim)
+                s[f"{p}.self_attn.grep_linear.bias"] = (8,)
+                s[f"{p}.self_attn.grep_a"] = (1, H, 1, 1)
+    return s
+
+
+def synth_weights(cfg: EncoderConfig, seed: int = 0) -> Dict[str, np.ndarray]:
+    """Seeded fp32 weights for every hot-path parameter."""
+    rng = np.random.default_rng(seed)
+    out: Dict[str, np.ndarray] = {}
+    for name, shape in param_shapes(cfg).items():
+        leaf = name.rsplit(".", 1)[-1]
+        if name.endswith("relative_attention_bias.weight"):
+            w = rng.standard_normal(shape) * 0.5
+        elif name.endswith("grep_a"):
+            w = 1.0 + 0.3 * rng.standard_normal(shape)
+        elif name.endswith("weight_g"):
+            # weight_norm gain: w[:,:,k] = g[k] * v[:,:,k] / ||v[:,:,k]||  → RMS(w) = g/sqrt(numel per tap)
+            d_out, d_in, _ = param_shapes(cfg)["encoder.pos_conv.0.weight_v"]
+            w = (1.0 + 0.2 * rng.standard_normal(shape)) * np.sqrt(d_out / shape[-1]) * 0.5
+        elif leaf == "weight" and len(shape) == 1:  # norm gains
+            w = 1.0 + 0.1 * rng.standard_normal(shape)
+        elif leaf == "bias":
+            w = 0.05 * rng.standard_normal(shape)
+        elif "conv_layers" in name:  # (out, in, k): keep unit variance through GELU (gain ~ sqrt(2.5))
+            fan_in = shape[1] * shape[2]
+            w = rng.standard_normal(shape) * np.sqrt(2.5 / fan_in)
+        elif leaf == "weight_v":
+            w = rng.standard_normal(shape)
+        else:  # linear (out, in)
+            gain = 2.0 if ".fc2." in name else 1.0
+            w = rng.standard_normal(shape) * np.sqrt(gain / shape[-1])
+        out[name] = np.ascontiguousarray(w, dtype=np.float32)
+    return out
+
+
+def synth_wavs(lengths: List[int], seed: int = 1234, dc: float = 0.0, scale: float = 1.0) -> List[np.ndarray]:
+    """Seeded gaussian 'waveforms' (the reference's own convention: ``torch.randn``,
+    s3prl/util/pseudo_data.py:70). numpy-generated so both sides can rebuild them offline."""
+    rng = np.random.default_rng(seed)
+    return [(rng.standard_normal(n) * scale + dc).astype(np.float32) for n in lengths]
+
+
+def pseudo_lengths(n: int = 2, min_secs: float = 1.0, max_secs: float = 3.0, seed: int = 0,
+                   sample_rate: int = 16000) -> List[int]:
+    """Lengths in the style of ``get_pseudo_wavs`` (s3prl/util/pseudo_data.py:52-77): n utterances
+    between min_secs and max_secs."""
+    rng = np.random.default_rng(seed)
+    lo, hi = int(min_secs * sample_rate), int(max_secs * sample_rate)
+    return [int(rng.integers(lo, hi + 1)) for _ in range(n)]
+
+
+# ------------------------------------------------------------------------------------------
+# named configurations
+# ------------------------------------------------------------------------------------------
+
+def named_config(name: str) -> EncoderConfig:
+    """Architectures named by BASELINE.json plus tiny variants of each for fast tests.
+
+    Large-model hyper-parameters are not in the reference tree (they live in the released
+    checkpoints); the values follow SURVEY §8c.
+    """
+    tiny_conv = [(64, 10, 5)] + [(64, 3, 2)] * 4 + [(64, 2, 2)] * 2
+    tiny = dict(conv_layers=tiny_conv, encoder_layers=3, encoder_embed_dim=128,
+                encoder_ffn_embed_dim=256, encoder_attention_heads=2, conv_pos=16, conv_pos_groups=4)
+    large = dict(extractor_mode="layer_norm", encoder_layers=24, encoder_embed_dim=1024,
+                 encoder_ffn_embed_dim=4096, encoder_attention_heads=16, layer_norm_first=True,
+                 normalize=True)
+    table = {
+        "hubert_base": dict(family="hubert"),
+        "wav2vec2_base": dict(family="wav2vec2"),
+        "wavlm_base": dict(family="wavlm"),
+        "wavlm_base_plus": dict(family="wavlm", relative_position_embedding=True, num_buckets=320,
+                                max_distance=800, gru_rel_pos=True),
+        "hubert_large": dict(family="hubert", conv_bias=False, **large),
+        "wav2vec2_large": dict(family="wav2vec2", conv_bias=True, **large),
+        "wavlm_large": dict(family="wavlm", conv_bias=False, relative_position_embedding=True,
+                            num_buckets=320, max_distance=800, gru_rel_pos=True, **large),
+        "tiny_hubert": dict(family="hubert", **tiny),
+        "tiny_wav2vec2": dict(family="wav2vec2", **tiny),
+        "tiny_hubert_large": dict(family="hubert", **{**tiny, "extractor_mode": "layer_norm",
+                                                      "layer_norm_first": True, "normalize": True,
+                                                      "conv_bias": True}),
+        "tiny_wav2vec2_large": dict(family="wav2vec2", **{**tiny, "extractor_mode": "layer_norm",
+                                                          "layer_norm_first": True, "normalize": True,
+                                                          "conv_bias": True}),
+        "tiny_wavlm": dict(family="wavlm", relative_position_embedding=True, num_buckets=32,
+                           max_distance=64, gru_rel_pos=True, **tiny),
+        "tiny_wavlm_large": dict(family="wavlm", relative_position_embedding=True, num_buckets=32,
+                                 max_distance=64, gru_rel_pos=True,
+                                 **{**tiny, "extractor_mode": "layer_norm", "layer_norm_first": True,
+                                    "normalize": True}),
+    }
+    if name not in table:
+        raise KeyError(f"unknown config {name!r}; have {sorted(table)}")
+    cfg = EncoderConfig(**table[name])
+    cfg.validate()
+    return cfg

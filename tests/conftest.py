@@ -1,0 +1,45 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+
+
+def golden_names():
+    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz"))
+
+
+def load_golden(name):
+    """Returns (meta, cfg, weights, wavs, golden arrays) — weights / wavs rebuilt from the stored seeds."""
+    from s3prl_amd.synth import named_config, synth_weights, synth_wavs
+
+    z = np.load(os.path.join(GOLDEN_DIR, f"{name}.npz"))
+    meta = json.loads(bytes(z["meta"]).decode())
+    cfg = named_config(meta["config"])
+    weights = synth_weights(cfg, meta["weight_seed"])
+    wavs = synth_wavs(meta["lengths"], meta["wav_seed"], dc=meta["dc"], scale=meta["scale"])
+    hs = [z[f"hs{l}"] for l in range(cfg.encoder_layers + 1)]
+    return meta, cfg, weights, wavs, hs, z["norms"]
+
+
+@pytest.fixture(scope="session")
+def golden_loader():
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            cache[name] = load_golden(name)
+        return cache[name]
+
+    return get

@@ -1,0 +1,154 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory by RUNNING THE REFERENCE (PyTorch CPU).
+
+Run in the build container only (it imports ``/root/reference``, which does not exist on the GPU box):
+
+    python tests/golden/make_golden.py            # all cases
+    python tests/golden/make_golden.py tiny_hubert_pad   # one case
+
+For every case the seeded numpy weights of ``s3prl_amd.synth.synth_weights`` are loaded into the
+reference model class, saved in the reference's converted-checkpoint format, and the
+reference ``UpstreamExpert(ckpt)(wavs)["hidden_states"]`` is recorded.  Tests rebuild the same weights
+and waveforms from the seeds stored in the fixture, so only outputs are committed.
+
+Nothing here is copied from the reference; it is only imported and executed.
+"""
+
+from __future__ import annotations
+
+import dataclasses
+import json
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from s3prl_amd.synth import named_config, synth_weights, synth_wavs  # noqa: E402
+
+REFERENCE = "/root/reference"
+
+# name → (config, weight seed, wav seed, lengths, (t_stride, c_stride) subsampling of stored tensors,
+#         waveform dc offset, waveform scale)
+CASES = {
+    "tiny_hubert_pad": ("tiny_hubert", 1, 11, [4000, 2345, 3111, 800], (1, 1), 0.0, 1.0),
+    "tiny_hubert_eq": ("tiny_hubert", 2, 12, [3200, 3200], (1, 1), 0.1, 0.5),
+    "tiny_wav2vec2_pad": ("tiny_wav2vec2", 3, 13, [4000, 2345, 3111, 800], (1, 1), 0.0, 1.0),
+    "tiny_wav2vec2_eq": ("tiny_wav2vec2", 4, 14, [2999, 2999], (1, 1), 0.0, 1.0),
+    "tiny_hubert_large_pad": ("tiny_hubert_large", 5, 15, [4000, 2345, 3111], (1, 1), 0.3, 2.0),
+    "tiny_wav2vec2_large_pad": ("tiny_wav2vec2_large", 6, 16, [3500, 4000, 1700], (1, 1), 0.0, 1.0),
+    "tiny_wavlm_pad": ("tiny_wavlm", 7, 17, [4000, 2345, 3111], (1, 1), 0.0, 1.0),
+    "tiny_wavlm_large_pad": ("tiny_wavlm_large", 8, 18, [4000, 2345, 3111], (1, 1), -0.2, 0.7),
+    "hubert_base_pseudo": ("hubert_base", 0, 21, [23456, 16000], (4, 8), 0.0, 1.0),
+    "wav2vec2_base_pseudo": ("wav2vec2_base", 0, 22, [20000, 27123], (4, 8), 0.0, 1.0),
+    "wavlm_base_plus_pseudo": ("wavlm_base_plus", 0, 23, [23456, 16000], (4, 8), 0.0, 1.0),
+    "hubert_large_pseudo": ("hubert_large", 0, 24, [16000, 12000], (4, 16), 0.0, 1.0),
+    "wavlm_large_pseudo": ("wavlm_large", 0, 25, [16000, 12000], (4, 16), 0.0, 1.0),
+}
+
+
+def _import_reference():
+    import torch  # noqa: F401
+
+    # s3prl/util/pseudo_data.py:15 imports torchaudio at module level; shim it.
+    sys.modules.setdefault("torchaudio", types.ModuleType("torchaudio"))
+    if REFERENCE not in sys.path:
+        sys.path.insert(0, REFERENCE)
+
+
+def build_reference_expert(cfg, weights, tmpdir):
+    """Instantiate the reference model for ``cfg``, load ``weights`` and return its UpstreamExpert."""
+    import torch
+
+    _import_reference()
+    conv_str = str([tuple(t) for t in cfg.conv_layers])
+    common = dict(
+        extractor_mode=cfg.extractor_mode, conv_bias=cfg.conv_bias, encoder_layers=cfg.encoder_layers,
+        encoder_embed_dim=cfg.encoder_embed_dim, encoder_ffn_embed_dim=cfg.encoder_ffn_embed_dim,
+        encoder_attention_heads=cfg.encoder_attention_heads, layer_norm_first=cfg.layer_norm_first,
+        conv_pos=cfg.conv_pos, conv_pos_groups=cfg.conv_pos_groups, conv_feature_layers=conv_str,
+    )
+    path = os.path.join(tmpdir, "ckpt.pt")
+    torch.manual_seed(0)
+    if cfg.family == "hubert":
+        from s3prl.upstream.hubert.hubert_model import HubertConfig, HubertModel, HubertPretrainingConfig
+        from s3prl.upstream.hubert.expert import UpstreamExpert
+
+        mc = HubertConfig(label_rate=50.0, final_dim=32, **common)
+        tc = HubertPretrainingConfig(label_rate=50.0, normalize=cfg.normalize)
+        model = HubertModel(mc, tc, [["a"] * 8])
+        _load(model, weights)
+        torch.save({"task_cfg": dataclasses.asdict(tc), "model_cfg": dataclasses.asdict(mc),
+                    "model_weight": model.state_dict(), "dictionaries_symbols": [["a"] * 8]}, path)
+    elif cfg.family == "wav2vec2":
+        from s3prl.upstream.wav2vec2.wav2vec2_model import AudioPretrainingConfig, Wav2Vec2Config, Wav2Vec2Model
+        from s3prl.upstream.wav2vec2.expert import UpstreamExpert
+
+        mc = Wav2Vec2Config(quantize_targets=True, final_dim=32, latent_vars=8, latent_groups=2, **common)
+        tc = AudioPretrainingConfig(normalize=cfg.normalize)
+        model = Wav2Vec2Model(mc)
+        _load(model, weights)
+        torch.save({"task_cfg": dataclasses.asdict(tc), "model_cfg": dataclasses.asdict(mc),
+                    "model_weight": model.state_dict()}, path)
+    else:
+        from s3prl.upstream.wavlm.WavLM import WavLM, WavLMConfig
+        from s3prl.upstream.wavlm.expert import UpstreamExpert
+
+        d = dict(common, normalize=cfg.normalize, relative_position_embedding=cfg.relative_position_embedding,
+                 num_buckets=cfg.num_buckets, max_distance=cfg.max_distance, gru_rel_pos=cfg.gru_rel_pos)
+        model = WavLM(WavLMConfig(d))
+        _load(model, weights)
+        torch.save({"cfg": d, "model": model.state_dict()}, path)
+    expert = UpstreamExpert(path).eval()
+    return expert, path
+
+
+def _load(model, weights):
+    import torch
+
+    sd = model.state_dict()
+    missing = [k for k in weights if k not in sd]
+    assert not missing, f"names not in the reference state_dict: {missing[:5]}"
+    for k, v in weights.items():
+        assert tuple(sd[k].shape) == tuple(v.shape), (k, sd[k].shape, v.shape)
+        sd[k] = torch.from_numpy(v.copy())
+    model.load_state_dict(sd)
+
+
+def reference_hidden_states(cfg, weights, wavs):
+    import torch
+
+    with tempfile.TemporaryDirectory() as tmp:
+        expert, _ = build_reference_expert(cfg, weights, tmp)
+        with torch.no_grad():
+            out = expert([torch.from_numpy(w.copy()) for w in wavs])
+    return [h.numpy() for h in out["hidden_states"]], out
+
+
+def make_case(name: str):
+    cfg_name, wseed, xseed, lengths, (ts, cs), dc, scale = CASES[name]
+    cfg = named_config(cfg_name)
+    weights = synth_weights(cfg, wseed)
+    wavs = synth_wavs(lengths, xseed, dc=dc, scale=scale)
+    hs, out = reference_hidden_states(cfg, weights, wavs)
+    assert len(hs) == cfg.encoder_layers + 1
+    meta = dict(config=cfg_name, weight_seed=wseed, wav_seed=xseed, lengths=lengths, t_stride=ts, c_stride=cs,
+                dc=dc, scale=scale, shape=list(hs[0].shape), reference="s3prl 0.4.18 @ /root/reference, torch CPU fp32")
+    arrays = {f"hs{l}": np.ascontiguousarray(h[:, ::ts, ::cs]) for l, h in enumerate(hs)}
+    # full-tensor norms so a subsampled fixture still pins the global scale of every layer
+    arrays["norms"] = np.array([np.linalg.norm(h.astype(np.float64)) for h in hs])
+    arrays["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    path = os.path.join(HERE, f"{name}.npz")
+    np.savez_compressed(path, **arrays)
+    print(f"{name}: {len(hs)} x {hs[0].shape} -> {os.path.getsize(path) / 1e3:.0f} kB")
+
+
+if __name__ == "__main__":
+    names = sys.argv[1:] or list(CASES)
+    for n in names:
+        make_case(n)

@@ -1,0 +1,56 @@
+"""The numpy oracle (oracle/encoder_oracle.py) against fixtures produced by RUNNING THE REFERENCE
+(tests/golden/make_golden.py, PyTorch CPU fp32).  This is what pins the oracle."""
+
+import numpy as np
+import pytest
+
+from conftest import golden_names
+from oracle import encoder_oracle as O
+
+# fp32-vs-fp32 of two different summation orders; the reference's own regression tolerance is atol 1e-2
+# (test/test_upstream.py:22)
+REL_TOL = 1e-4
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_oracle_matches_reference_golden(name, golden_loader):
+    meta, cfg, weights, wavs, golden, norms = golden_loader(name)
+    hs = O.forward(cfg, weights, wavs, dtype=np.float32)
+    assert len(hs) == cfg.encoder_layers + 1 == len(golden)
+    assert list(hs[0].shape) == meta["shape"]
+    ts, cs = meta["t_stride"], meta["c_stride"]
+    for l, (h, g) in enumerate(zip(hs, golden)):
+        assert h.dtype == np.float32
+        err = O.rel_err(h[:, ::ts, ::cs], g)
+        assert err < REL_TOL, f"{name} layer {l}: rel-err {err:.3e}"
+        full = np.linalg.norm(h.astype(np.float64))
+        assert abs(full - norms[l]) / norms[l] < REL_TOL
+
+
+def test_frames_and_mask_rules():
+    """Closed forms of SURVEY A.2 (hubert chunk rule vs wav2vec2 conv-length rule)."""
+    from s3prl_amd.synth import named_config
+
+    hub, w2v = named_config("hubert_base"), named_config("wav2vec2_base")
+    assert hub.conv_lengths(160000) == [31999, 15999, 7999, 3999, 1999, 999, 499]
+    assert hub.conv_lengths(240000)[-1] == 749
+    assert hub.num_frames(800) == 2  # EXTRA_SHORT_SEC = 0.05 s (test/test_upstream.py:24)
+    assert hub.downsample_rate == 320
+    # len = 16123 in a 160000-sample batch: HuBERT keeps 51 frames, wav2vec2 50
+    assert hub.valid_frames(16123, 160000) == 51
+    assert w2v.valid_frames(16123, 160000) == 50
+    # n_max = 32000 → T = 99, chunk = 323
+    assert hub.num_frames(32000) == 99 and hub.valid_frames(32000, 32000) == 99
+    assert hub.valid_frames(323 * 10 + 1, 32000) == 11
+
+
+def test_shard_padded_to_global_max_reproduces_full_batch(golden_loader):
+    """a data-parallel shard must be padded to the GLOBAL n_max; then its rows equal
+    the single-batch reference rows."""
+    meta, cfg, weights, wavs, golden, _ = golden_loader("tiny_hubert_pad")
+    n_max = max(meta["lengths"])
+    shard = O.forward(cfg, weights, wavs[2:], dtype=np.float32, n_max=n_max)
+    for l, g in enumerate(golden):
+        assert O.rel_err(shard[l], g[2:]) < REL_TOL
+    local = O.forward(cfg, weights, wavs[2:], dtype=np.float32)  # padded to the shard's own max: different
+    assert local[0].shape[1] != golden[0].shape[1] or O.rel_err(local[0], golden[0][2:]) > 1e-2
