@@ -1,0 +1,153 @@
+/*
+ * s3enc.h — C ABI of libs3enc.so: the MI355X (gfx950) speech-SSL upstream encoder.
+ *
+ * One hot path of s3prl, behind plain C:  raw 16 kHz waveforms  ->  the list of per-layer
+ * hidden_states of a wav2vec 2.0 / HuBERT / WavLM encoder.  The reference is pure Python on top of
+ * PyTorch ATen, so there is no reference FFI to bind; each entry point below names the reference
+ * Python interface it stands in for (paths relative to the s3prl tree).
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on failure; s3enc_last_error() (thread-local)
+ *     describes the last failure.  Nothing throws across this boundary.
+ *   - pointers documented "device" are HIP device pointers on the handle's GPU; "host" are host pointers.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Work is enqueued
+ *     asynchronously on it and ordered with the caller's own work on that stream.
+ *   - a handle is not re-entrant; distinct handles are independent (one per GPU / per process rank).
+ *   - there is no CPU fallback: without a gfx950 device s3enc_create fails.
+ */
+#ifndef S3ENC_H
+#define S3ENC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define S3ENC_VERSION 1
+#define S3ENC_MAX_CONV 16
+
+typedef struct s3enc_encoder* s3enc_handle;
+
+enum { S3ENC_HUBERT = 0, S3ENC_WAV2VEC2 = 1, S3ENC_WAVLM = 2 };
+/* arithmetic type of the GEMM / attention operands; accumulation, norms, softmax, GELU and the residual
+ * stream are always fp32 (the reference's Fp32GroupNorm / Fp32LayerNorm / fp32 softmax guards,
+ * wav2vec2_model.py:1826-1853,1899-1900). */
+enum { S3ENC_F32 = 0, S3ENC_BF16 = 1, S3ENC_F16 = 2 };
+
+/* Hyper-parameters that select kernel variants.
+ * Replaces: HubertConfig / HubertPretrainingConfig (upstream/hubert/hubert_model.py:33-278),
+ *           Wav2Vec2Config / AudioPretrainingConfig (upstream/wav2vec2/wav2vec2_model.py:2103-2350,3325-3345),
+ *           WavLMConfig (upstream/wavlm/WavLM.py:162-245). */
+typedef struct s3enc_config {
+    int32_t family;                        /* S3ENC_HUBERT / WAV2VEC2 / WAVLM: selects the frame-mask rule */
+    int32_t n_conv;                        /* number of conv feature layers (7) */
+    int32_t conv_dim;                      /* channels of every conv layer (512) */
+    int32_t conv_kernel[S3ENC_MAX_CONV];   /* (10,3,3,3,3,2,2) */
+    int32_t conv_stride[S3ENC_MAX_CONV];   /* (5,2,2,2,2,2,2) */
+    int32_t extractor_layer_norm;          /* 0: "default" (GroupNorm after conv0); 1: "layer_norm" */
+    int32_t conv_bias;
+    int32_t encoder_layers;
+    int32_t embed_dim;
+    int32_t ffn_dim;
+    int32_t heads;
+    int32_t layer_norm_first;              /* 0: post-LN (base); 1: pre-LN (large) */
+    int32_t conv_pos;                      /* positional conv kernel (128) */
+    int32_t conv_pos_groups;               /* (16) */
+    int32_t normalize;                     /* per-utterance waveform layer-norm (task_cfg.normalize) */
+    int32_t rel_pos;                       /* WavLM: relative_position_embedding */
+    int32_t num_buckets;
+    int32_t max_distance;
+    int32_t gru_rel_pos;
+    int32_t compute_dtype;                 /* S3ENC_F32 / BF16 / F16 */
+} s3enc_config;
+
+/* A named fp32 host tensor of the checkpoint, named exactly like the reference state_dict entry
+ * ("encoder.layers.3.fc1.weight", ...).  Replaces model.load_state_dict(...)
+ * (upstream/hubert/convert.py:37-56, wav2vec2/convert.py:26-39, wavlm/expert.py:37-40). */
+typedef struct s3enc_tensor {
+    const char* name;
+    const float* data;  /* host, contiguous, row-major */
+    int32_t ndim;
+    int64_t shape[4];
+} s3enc_tensor;
+
+int s3enc_version(void);
+const char* s3enc_last_error(void);
+
+/* Build an encoder on GPU `device`: packs the weights (folds weight-norm, concatenates q/k/v, folds the
+ * 1/sqrt(head_dim) query scale, re-lays conv weights tap-major, converts to the compute dtype) and uploads them.
+ * Replaces UpstreamExpert.__init__ (hubert/expert.py:27-51, wav2vec2/expert.py:21-56, wavlm/expert.py:34-54). */
+int s3enc_create(const s3enc_config* cfg, const s3enc_tensor* tensors, int32_t n_tensors, int32_t device,
+                 s3enc_handle* out);
+int s3enc_destroy(s3enc_handle h);
+
+/* T = frames produced for an n-sample input: floor((L-k)/s)+1 through the conv stack
+ * (wav2vec2_model.py:2610-2624).  get_downsample_rates() is the product of the strides (320). */
+int s3enc_num_frames(s3enc_handle h, int64_t n_samples, int32_t* T);
+int s3enc_downsample_rate(s3enc_handle h, int32_t* rate);
+/* Un-masked frames of an utterance of `length` samples in a batch padded to `n_max`:
+ * HuBERT/WavLM forward_padding_mask (hubert_model.py:454-464, WavLM.py:339-349), wav2vec2 conv-length rule
+ * (wav2vec2_model.py:2652-2669). */
+int s3enc_valid_frames(s3enc_handle h, int64_t length, int64_t n_max, int32_t* valid);
+
+/* The forward.  Replaces UpstreamExpert.forward + the hook capture of UpstreamBase.__call__
+ * (hubert/expert.py:56-72, upstream/interfaces.py:100-131).
+ *   wavs      host array of B device pointers, wavs[b] -> lengths[b] fp32 samples (borrowed, read-only)
+ *   lengths   host array of B sample counts
+ *   n_max     pad-to length; 0 = max(lengths).  A data-parallel shard passes the GLOBAL batch maximum.
+ *   out       device fp32; hidden_states[l] is the contiguous (B, T, D) block at out + l*layer_stride,
+ *             l = 0..encoder_layers (layer inputs, then the encoder output)
+ *   layer_stride  in elements, >= B*T*D
+ */
+int s3enc_forward(s3enc_handle h, const float* const* wavs, const int64_t* lengths, int32_t B, int64_t n_max,
+                  float* out, int64_t layer_stride, void* stream);
+
+/* Same, for a zero-padded (B, row_stride) device buffer (what pad_sequence builds, hubert/expert.py:66). */
+int s3enc_forward_padded(s3enc_handle h, const float* pcm, int64_t row_stride, const int64_t* lengths, int32_t B,
+                         int64_t n_max, float* out, int64_t layer_stride, void* stream);
+
+/* ---- measurement ------------------------------------------------------------------------------------
+ * With profiling on, every kernel launch of the next forwards is bracketed by HIP events on the launch
+ * stream; s3enc_profile_read synchronises and returns per-kernel-kind totals. */
+int s3enc_profile_enable(s3enc_handle h, int32_t on);
+int s3enc_profile_reset(s3enc_handle h);
+typedef struct s3enc_profile_entry {
+    char name[48];
+    int64_t launches;
+    double ms;     /* summed event time */
+    double flops;  /* algorithmic FLOPs of those launches (2*M*N*K etc.; 0 for byte-bound kernels) */
+    double bytes;  /* algorithmic HBM bytes of those launches (operands read once + outputs written once) */
+} s3enc_profile_entry;
+int s3enc_profile_read(s3enc_handle h, s3enc_profile_entry* entries, int32_t max_entries, int32_t* n_entries);
+
+/* Copy an intermediate of the LAST forward to the host as fp32 (test hook): "conv0".."conv6", "feat_ln",
+ * "proj", "posconv", "qkv0", "attn0".  Synchronises. */
+int s3enc_debug_tap(s3enc_handle h, const char* name, float* host_out, int64_t max_elems, int64_t* n_elems);
+
+/* ---- single-kernel entry points (parity tests of each HIP kernel against the oracle) -------------------
+ * All pointers are device pointers; dtype is S3ENC_F32/BF16/F16 for the 16-bit-capable operands
+ * (16-bit data are raw uint16). */
+
+/* out[b][m][n] = epilogue( sum_k A[b][m][k] * W[n][k] ):  A rows start at A + b*a_batch_stride + m*lda
+ * (elements; lda < K expresses an overlapping strided-conv window), W is (N, K) row-major.
+ * epilogue: + bias[n]; GELU if act; + residual (fp32, same indexing as out32); rows m >= row_limit[b] -> 0.
+ * Writes out32 (fp32) and/or out16 (dtype) when non-NULL. */
+int s3enc_op_gemm(int32_t dtype, const void* A, int64_t lda, int64_t a_batch_stride, const void* W,
+                  const float* bias, int32_t M, int32_t N, int32_t K, int32_t batches, int32_t act,
+                  const float* residual, const int32_t* row_limit, float* out32, void* out16, int64_t ldo,
+                  int64_t o_batch_stride, void* stream);
+
+/* Row LayerNorm over C (eps 1e-5, biased variance), optional erf-GELU, fp32 in, fp32 and/or dtype out. */
+int s3enc_op_layernorm(int32_t dtype, const float* x, const float* gamma, const float* beta, int32_t rows,
+                       int32_t C, int32_t act, float* out32, void* out16, void* stream);
+
+/* Multi-head self-attention on a fused (B*T, 3D) q|k|v buffer (q pre-scaled), head_dim 64, keys >= valid[b]
+ * masked; optional WavLM gated relative-position bias: score += gate[b][h][i] * table[h][(j-i)+(T-1)]. */
+int s3enc_op_attention(int32_t dtype, const void* qkv, void* out, const int32_t* valid, int32_t B, int32_t T,
+                       int32_t H, const float* bias_table, const float* gate, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* S3ENC_H */

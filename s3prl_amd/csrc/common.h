@@ -1,0 +1,72 @@
+// common.h — shared device helpers for the gfx950 kernels of libs3enc.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace s3 {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+
+enum DType : int { F32 = 0, BF16 = 1, F16 = 2 };
+
+constexpr int WAVE = 64;
+constexpr float LN_EPS = 1e-5f;
+
+// ---- 16-bit storage tags: data live in memory as raw uint16 -----------------------------------------
+struct bf16_tag {};
+struct f16_tag {};
+
+__device__ __forceinline__ u16 f32_to_bf16(float f) {
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u16)((u >> 16) | 0x40);  // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);  // round to nearest even
+    return (u16)(u >> 16);
+}
+__device__ __forceinline__ float bf16_to_f32(u16 h) { return __uint_as_float(((unsigned)h) << 16); }
+__device__ __forceinline__ u16 f32_to_f16(float f) {
+    _Float16 h = (_Float16)f;
+    return __builtin_bit_cast(u16, h);
+}
+__device__ __forceinline__ float f16_to_f32(u16 h) { return (float)__builtin_bit_cast(_Float16, h); }
+
+template <typename T> struct Cvt;
+template <> struct Cvt<float> {
+    typedef float store_t;
+    static __device__ __forceinline__ float to(float f) { return f; }
+    static __device__ __forceinline__ float from(float f) { return f; }
+};
+template <> struct Cvt<bf16_tag> {
+    typedef u16 store_t;
+    static __device__ __forceinline__ u16 to(float f) { return f32_to_bf16(f); }
+    static __device__ __forceinline__ float from(u16 h) { return bf16_to_f32(h); }
+};
+template <> struct Cvt<f16_tag> {
+    typedef u16 store_t;
+    static __device__ __forceinline__ u16 to(float f) { return f32_to_f16(f); }
+    static __device__ __forceinline__ float from(u16 h) { return f16_to_f32(h); }
+};
+
+// erf-GELU in fp32: nn.GELU() / F.gelu(x.float()) on the reference path.
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+}  // namespace s3

@@ -1,0 +1,1016 @@
+// engine.cpp — the C ABI of libs3enc (include/s3enc.h): handle, weight packer, workspace, forward schedule.
+//
+// Forward schedule (all launches on the caller's stream, no host synchronisation inside):
+//   table upload -> wav stats -> [GroupNorm lag sums] -> conv0 -> conv1..6 (implicit GEMM, GELU fused)
+//   -> LayerNorm(C) -> post_extract_proj (+bias, padded frames zeroed) -> pos-conv (+GELU, +residual)
+//   -> [post-LN: encoder.layer_norm] -> NL x { q|k|v GEMM, attention, out_proj(+residual), LN, fc1(+GELU),
+//   fc2(+residual), LN }  with every hidden-state tap written straight into the caller's (NL+1, B, T, D) slab.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/s3enc.h"
+#include "kernels.h"
+
+using namespace s3;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(const std::string& msg) {
+    g_err = msg;
+    return 1;
+}
+
+#define HIP_TRY(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess) {                                                                        \
+            char _b[512];                                                                              \
+            snprintf(_b, sizeof(_b), "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return fail(_b);                                                                           \
+        }                                                                                              \
+    } while (0)
+
+// ---- host-side dtype conversion -------------------------------------------------------------------------
+inline uint16_t h_bf16(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+inline uint16_t h_f16(float f) {
+    _Float16 h = (_Float16)f;
+    uint16_t r;
+    memcpy(&r, &h, 2);
+    return r;
+}
+inline float h_from16(uint16_t v, int dtype) {
+    if (dtype == BF16) {
+        uint32_t u = ((uint32_t)v) << 16;
+        float f;
+        memcpy(&f, &u, 4);
+        return f;
+    }
+    _Float16 h;
+    memcpy(&h, &v, 2);
+    return (float)h;
+}
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes) {
+        o.p = nullptr;
+        o.bytes = 0;
+    }
+    hipError_t ensure(size_t n) {
+        if (n <= bytes) return hipSuccess;
+        if (p) {
+            hipError_t e = hipFree(p);  // implicit device sync: nothing in flight still uses it
+            p = nullptr;
+            bytes = 0;
+            if (e != hipSuccess) return e;
+        }
+        hipError_t e = hipMalloc(&p, n);
+        if (e == hipSuccess) bytes = n;
+        return e;
+    }
+};
+
+hipError_t upload_f32(DevBuf& d, const std::vector<float>& v) {
+    hipError_t e = d.ensure(v.size() * 4 + 16);
+    if (e != hipSuccess) return e;
+    return hipMemcpy(d.p, v.data(), v.size() * 4, hipMemcpyHostToDevice);
+}
+hipError_t upload_cvt(DevBuf& d, const std::vector<float>& v, int dtype) {
+    if (dtype == F32) return upload_f32(d, v);
+    std::vector<uint16_t> h(v.size());
+    if (dtype == BF16)
+        for (size_t i = 0; i < v.size(); ++i) h[i] = h_bf16(v[i]);
+    else
+        for (size_t i = 0; i < v.size(); ++i) h[i] = h_f16(v[i]);
+    hipError_t e = d.ensure(h.size() * 2 + 16);
+    if (e != hipSuccess) return e;
+    return hipMemcpy(d.p, h.data(), h.size() * 2, hipMemcpyHostToDevice);
+}
+
+struct LayerW {
+    DevBuf wqkv, bqkv, wo, bo, ln1g, ln1b, w1, b1, w2, b2, ln2g, ln2b;
+    DevBuf grep_w, grep_b, grep_a;
+};
+struct ConvW {
+    DevBuf w, bias, lng, lnb;  // w: conv0 fp32 [C][k]; conv>=1 compute dtype [C][k*Cin]
+    bool has_bias = false;
+};
+
+struct ProfRec {
+    int kind;
+    hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct s3enc_encoder {
+    s3enc_config cfg;
+    int device = 0;
+    int dtype = F32;
+    int es = 4;  // element size of the compute dtype
+    std::vector<ConvW> conv;
+    DevBuf gn_g, gn_b;
+    DevBuf fln_g, fln_b, proj_w, proj_b, pos_w, pos_b, eln_g, eln_b;
+    std::vector<LayerW> layers;
+    std::vector<float> rel_emb;  // host copy of relative_attention_bias.weight [buckets][H]
+    DevBuf rel_table;
+    int rel_table_T = -1;
+
+    DevBuf ws;      // activation workspace
+    DevBuf small;   // tables, stats
+    void* pinned = nullptr;  // host staging ring
+    static constexpr int RING = 4;
+    size_t slot_bytes = 0;
+    hipEvent_t slot_ev[RING] = {};
+    int slot_next = 0;
+
+    // profiling
+    bool prof = false;
+    std::vector<std::string> kinds;
+    std::vector<double> kflops, kbytes;
+    std::vector<long> klaunches;
+    std::vector<ProfRec> recs;
+
+    // debug taps of the last forward
+    struct Tap {
+        const void* p;
+        long elems;
+        int dtype;
+    };
+    std::map<std::string, Tap> taps;
+
+    ~s3enc_encoder() {
+        for (auto& r : recs) {
+            (void)hipEventDestroy(r.a);
+            (void)hipEventDestroy(r.b);
+        }
+        for (int i = 0; i < RING; ++i)
+            if (slot_ev[i]) (void)hipEventDestroy(slot_ev[i]);
+        if (pinned) (void)hipHostFree(pinned);
+    }
+
+    int kind_id(const char* name) {
+        for (size_t i = 0; i < kinds.size(); ++i)
+            if (kinds[i] == name) return (int)i;
+        kinds.push_back(name);
+        kflops.push_back(0);
+        kbytes.push_back(0);
+        klaunches.push_back(0);
+        return (int)kinds.size() - 1;
+    }
+};
+
+namespace {
+
+struct Prof {
+    s3enc_encoder* e;
+    hipStream_t st;
+    int idx = -1;
+    Prof(s3enc_encoder* enc, hipStream_t s, const char* kind, double flops, double bytes) : e(enc), st(s) {
+        if (!e || !e->prof) return;
+        const int k = e->kind_id(kind);
+        e->kflops[k] += flops;
+        e->kbytes[k] += bytes;
+        e->klaunches[k] += 1;
+        ProfRec r;
+        r.kind = k;
+        if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+        (void)hipEventRecord(r.a, st);
+        e->recs.push_back(r);
+        idx = (int)e->recs.size() - 1;
+    }
+    ~Prof() {
+        if (idx >= 0) (void)hipEventRecord(e->recs[idx].b, st);
+    }
+};
+
+// ---- checkpoint lookup ---------------------------------------------------------------------------------------
+struct Ckpt {
+    std::map<std::string, const s3enc_tensor*> m;
+    const s3enc_tensor* get(const std::string& n) const {
+        auto it = m.find(n);
+        return it == m.end() ? nullptr : it->second;
+    }
+};
+long numel(const s3enc_tensor* t) {
+    long n = 1;
+    for (int i = 0; i < t->ndim; ++i) n *= t->shape[i];
+    return n;
+}
+bool fetch(const Ckpt& c, const std::string& name, long expect, std::vector<float>& out, std::string& err) {
+    const s3enc_tensor* t = c.get(name);
+    if (!t) {
+        err = "checkpoint is missing tensor '" + name + "'";
+        return false;
+    }
+    if (numel(t) != expect) {
+        err = "tensor '" + name + "' has " + std::to_string(numel(t)) + " elements, expected " + std::to_string(expect);
+        return false;
+    }
+    out.assign(t->data, t->data + expect);
+    return true;
+}
+
+long conv_len(const s3enc_config& c, long n, int upto /*exclusive*/) {
+    for (int i = 0; i < upto; ++i) n = n >= c.conv_kernel[i] ? (n - c.conv_kernel[i]) / c.conv_stride[i] + 1 : 0;
+    return n;
+}
+
+int valid_frames(const s3enc_config& c, long length, long n_max) {
+    const long T = conv_len(c, n_max, c.n_conv);
+    if (T <= 0) return 0;
+    long v;
+    if (c.family == S3ENC_WAV2VEC2) {
+        v = conv_len(c, length, c.n_conv);  // wav2vec2_model.py:2652-2669
+    } else {
+        const long chunk = n_max / T;  // hubert_model.py:454-464
+        v = (length + chunk - 1) / chunk;
+    }
+    if (v > T) v = T;
+    if (v < 0) v = 0;
+    return (int)v;
+}
+
+int check_config(const s3enc_config& c) {
+    if (c.family < 0 || c.family > 2) return fail("config: unknown family");
+    if (c.n_conv < 2 || c.n_conv > S3ENC_MAX_CONV) return fail("config: n_conv out of range");
+    if (c.conv_kernel[0] != 10) return fail("config: the conv0 kernel is specialised for kernel width 10");
+    if (c.conv_dim % 32 || c.conv_dim > 1024) return fail("config: conv_dim must be a multiple of 32, <= 1024");
+    if (c.heads <= 0 || c.embed_dim != c.heads * 64) return fail("config: head_dim must be 64");
+    if (c.ffn_dim % 8) return fail("config: ffn_dim must be a multiple of 8");
+    if (c.conv_pos_groups <= 0 || c.embed_dim % c.conv_pos_groups) return fail("config: embed_dim % conv_pos_groups != 0");
+    const int dg = c.embed_dim / c.conv_pos_groups;
+    if (dg != 32 && dg != 48 && dg != 64) return fail("config: embed_dim/conv_pos_groups must be 32, 48 or 64");
+    if (c.conv_pos < 1 || c.conv_pos > 256) return fail("config: conv_pos out of range");
+    if (c.compute_dtype < 0 || c.compute_dtype > 2) return fail("config: unknown compute_dtype");
+    if (c.encoder_layers < 1) return fail("config: encoder_layers < 1");
+    if (c.rel_pos && c.family != S3ENC_WAVLM) return fail("config: rel_pos is a WavLM feature");
+    if (c.rel_pos && (c.num_buckets < 4 || c.max_distance <= c.num_buckets / 4))
+        return fail("config: bad num_buckets / max_distance");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int s3enc_version(void) { return S3ENC_VERSION; }
+const char* s3enc_last_error(void) { return g_err.c_str(); }
+
+int s3enc_create(const s3enc_config* cfg, const s3enc_tensor* tensors, int32_t n_tensors, int32_t device, s3enc_handle* out) {
+    if (!cfg || !tensors || !out) return fail("s3enc_create: null argument");
+    *out = nullptr;
+    if (check_config(*cfg)) return 1;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail("s3enc_create: no HIP device visible — libs3enc has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail("s3enc_create: device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(std::string("s3enc_create: kernels are built for gfx950 only, device is ") + prop.gcnArchName);
+
+    Ckpt ck;
+    for (int i = 0; i < n_tensors; ++i)
+        if (tensors[i].name && tensors[i].data) ck.m[tensors[i].name] = &tensors[i];
+
+    s3enc_encoder* e = new s3enc_encoder();
+    e->cfg = *cfg;
+    e->device = device;
+    e->dtype = cfg->compute_dtype;
+    e->es = e->dtype == F32 ? 4 : 2;
+    const s3enc_config& c = e->cfg;
+    const int C = c.conv_dim, D = c.embed_dim, F = c.ffn_dim, H = c.heads;
+    std::string err;
+    std::vector<float> t, t2;
+#define GET(name, n, vec)                  \
+    if (!fetch(ck, name, n, vec, err)) {   \
+        delete e;                          \
+        return fail(err);                  \
+    }
+#define UP(call)                                                     \
+    do {                                                             \
+        hipError_t _e = (call);                                      \
+        if (_e != hipSuccess) {                                      \
+            delete e;                                                \
+            return fail(std::string("weight upload failed: ") + hipGetErrorString(_e)); \
+        }                                                            \
+    } while (0)
+
+    // ---- conv feature extractor ----
+    e->conv.resize(c.n_conv);
+    for (int i = 0; i < c.n_conv; ++i) {
+        const std::string p = "feature_extractor.conv_layers." + std::to_string(i);
+        const int cin = i == 0 ? 1 : C, k = c.conv_kernel[i];
+        GET(p + ".0.weight", (long)C * cin * k, t);
+        if (i == 0) {
+            UP(upload_f32(e->conv[i].w, t));  // [C][k]
+        } else {
+            // re-lay (Cout, Cin, k) tap-major: W'[co][j*Cin + ci], the K order of the channel-last implicit GEMM
+            t2.resize(t.size());
+            for (int co = 0; co < C; ++co)
+                for (int ci = 0; ci < cin; ++ci)
+                    for (int j = 0; j < k; ++j) t2[((long)co * k + j) * cin + ci] = t[((long)co * cin + ci) * k + j];
+            UP(upload_cvt(e->conv[i].w, t2, e->dtype));
+        }
+        if (c.conv_bias) {
+            GET(p + ".0.bias", C, t);
+            UP(upload_f32(e->conv[i].bias, t));
+            e->conv[i].has_bias = true;
+        }
+        if (c.extractor_layer_norm) {
+            GET(p + ".2.1.weight", C, t);
+            UP(upload_f32(e->conv[i].lng, t));
+            GET(p + ".2.1.bias", C, t);
+            UP(upload_f32(e->conv[i].lnb, t));
+        } else if (i == 0) {
+            GET(p + ".2.weight", C, t);
+            UP(upload_f32(e->gn_g, t));
+            GET(p + ".2.bias", C, t);
+            UP(upload_f32(e->gn_b, t));
+        }
+    }
+    GET("layer_norm.weight", C, t);
+    UP(upload_f32(e->fln_g, t));
+    GET("layer_norm.bias", C, t);
+    UP(upload_f32(e->fln_b, t));
+    GET("post_extract_proj.weight", (long)D * C, t);
+    UP(upload_cvt(e->proj_w, t, e->dtype));
+    GET("post_extract_proj.bias", D, t);
+    UP(upload_f32(e->proj_b, t));
+
+    // ---- positional conv: fold weight_norm(dim=2), pack [G][K][Dg/16][Dg][16] ----
+    {
+        const int K = c.conv_pos, G = c.conv_pos_groups, Dg = D / G;
+        std::vector<float> g, v;
+        GET("encoder.pos_conv.0.weight_g", K, g);
+        GET("encoder.pos_conv.0.weight_v", (long)D * Dg * K, v);
+        std::vector<double> nrm(K, 0.0);
+        for (long i = 0; i < (long)D * Dg; ++i)
+            for (int k = 0; k < K; ++k) nrm[k] += (double)v[i * K + k] * v[i * K + k];
+        for (int k = 0; k < K; ++k) nrm[k] = (double)g[k] / std::sqrt(nrm[k]);
+        t2.assign((size_t)G * K * Dg * Dg, 0.f);
+        for (int gi = 0; gi < G; ++gi)
+            for (int n = 0; n < Dg; ++n)
+                for (int ci = 0; ci < Dg; ++ci)
+                    for (int k = 0; k < K; ++k) {
+                        const float w = (float)(v[((long)(gi * Dg + n) * Dg + ci) * K + k] * nrm[k]);
+                        const int cc = ci / 16, e16 = ci % 16;
+                        t2[((((long)gi * K + k) * (Dg / 16) + cc) * Dg + n) * 16 + e16] = w;
+                    }
+        UP(upload_f32(e->pos_w, t2));
+        GET("encoder.pos_conv.0.bias", D, t);
+        UP(upload_f32(e->pos_b, t));
+    }
+    GET("encoder.layer_norm.weight", D, t);
+    UP(upload_f32(e->eln_g, t));
+    GET("encoder.layer_norm.bias", D, t);
+    UP(upload_f32(e->eln_b, t));
+
+    // ---- transformer layers ----
+    e->layers.resize(c.encoder_layers);
+    const float qscale = 1.0f / std::sqrt((float)(D / H));
+    for (int l = 0; l < c.encoder_layers; ++l) {
+        const std::string p = "encoder.layers." + std::to_string(l);
+        LayerW& L = e->layers[l];
+        std::vector<float> w(3L * D * D), bb(3L * D);
+        const char* names[3] = {"q_proj", "k_proj", "v_proj"};
+        for (int s = 0; s < 3; ++s) {
+            GET(p + ".self_attn." + names[s] + ".weight", (long)D * D, t);
+            GET(p + ".self_attn." + names[s] + ".bias", D, t2);
+            const float sc = s == 0 ? qscale : 1.f;  // q *= head_dim^-0.5 folded into W_q, b_q
+            for (long i = 0; i < (long)D * D; ++i) w[(long)s * D * D + i] = t[i] * sc;
+            for (int i = 0; i < D; ++i) bb[(long)s * D + i] = t2[i] * sc;
+        }
+        UP(upload_cvt(L.wqkv, w, e->dtype));
+        UP(upload_f32(L.bqkv, bb));
+        GET(p + ".self_attn.out_proj.weight", (long)D * D, t);
+        UP(upload_cvt(L.wo, t, e->dtype));
+        GET(p + ".self_attn.out_proj.bias", D, t);
+        UP(upload_f32(L.bo, t));
+        GET(p + ".self_attn_layer_norm.weight", D, t);
+        UP(upload_f32(L.ln1g, t));
+        GET(p + ".self_attn_layer_norm.bias", D, t);
+        UP(upload_f32(L.ln1b, t));
+        GET(p + ".fc1.weight", (long)F * D, t);
+        UP(upload_cvt(L.w1, t, e->dtype));
+        GET(p + ".fc1.bias", F, t);
+        UP(upload_f32(L.b1, t));
+        GET(p + ".fc2.weight", (long)D * F, t);
+        UP(upload_cvt(L.w2, t, e->dtype));
+        GET(p + ".fc2.bias", D, t);
+        UP(upload_f32(L.b2, t));
+        GET(p + ".final_layer_norm.weight", D, t);
+        UP(upload_f32(L.ln2g, t));
+        GET(p + ".final_layer_norm.bias", D, t);
+        UP(upload_f32(L.ln2b, t));
+        if (c.rel_pos && c.gru_rel_pos) {
+            GET(p + ".self_attn.grep_linear.weight", 8 * 64, t);
+            UP(upload_f32(L.grep_w, t));
+            GET(p + ".self_attn.grep_linear.bias", 8, t);
+            UP(upload_f32(L.grep_b, t));
+            GET(p + ".self_attn.grep_a", H, t);
+            UP(upload_f32(L.grep_a, t));
+        }
+    }
+    if (c.rel_pos) {
+        GET("encoder.layers.0.self_attn.relative_attention_bias.weight", (long)c.num_buckets * H, e->rel_emb);
+    }
+#undef GET
+#undef UP
+    for (int i = 0; i < s3enc_encoder::RING; ++i) {
+        if (hipEventCreateWithFlags(&e->slot_ev[i], hipEventDisableTiming) != hipSuccess) {
+            delete e;
+            return fail("hipEventCreate failed");
+        }
+    }
+    *out = e;
+    return 0;
+}
+
+int s3enc_destroy(s3enc_handle h) {
+    if (!h) return 0;
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+    delete h;
+    return 0;
+}
+
+int s3enc_num_frames(s3enc_handle h, int64_t n_samples, int32_t* T) {
+    if (!h || !T) return fail("s3enc_num_frames: null argument");
+    *T = (int32_t)conv_len(h->cfg, n_samples, h->cfg.n_conv);
+    return 0;
+}
+int s3enc_downsample_rate(s3enc_handle h, int32_t* rate) {
+    if (!h || !rate) return fail("s3enc_downsample_rate: null argument");
+    int r = 1;
+    for (int i = 0; i < h->cfg.n_conv; ++i) r *= h->cfg.conv_stride[i];
+    *rate = r;
+    return 0;
+}
+int s3enc_valid_frames(s3enc_handle h, int64_t length, int64_t n_max, int32_t* valid) {
+    if (!h || !valid) return fail("s3enc_valid_frames: null argument");
+    *valid = valid_frames(h->cfg, length, n_max);
+    return 0;
+}
+
+}  // extern "C"
+
+namespace {
+
+// bump allocator over the workspace
+struct Bump {
+    char* base;
+    size_t off = 0;
+    explicit Bump(void* b) : base((char*)b) {}
+    void* take(size_t bytes) {
+        void* p = base ? base + off : nullptr;
+        off += (bytes + 255) & ~(size_t)255;
+        return p;
+    }
+};
+
+// WavLM bucket table: table[h][idx], idx = (j - i) + (T-1)   (wavlm/modules.py:418-462)
+void build_rel_table(const s3enc_config& c, const std::vector<float>& emb, int T, std::vector<float>& table) {
+    const int H = c.heads, nb = c.num_buckets / 2, max_exact = nb / 2;
+    table.resize((size_t)H * (2 * T - 1));
+    const float denom = (float)std::log((double)c.max_distance / (double)max_exact);
+    for (int idx = 0; idx < 2 * T - 1; ++idx) {
+        const int rel = idx - (T - 1);
+        int bucket = rel > 0 ? nb : 0;
+        const int a = rel < 0 ? -rel : rel;
+        if (a < max_exact) {
+            bucket += a;
+        } else {
+            float v = std::log((float)a / (float)max_exact);
+            v = v / denom;
+            v = v * (float)(nb - max_exact);
+            int large = max_exact + (int)v;
+            if (large > nb - 1) large = nb - 1;
+            bucket += large;
+        }
+        for (int h = 0; h < H; ++h) table[(size_t)h * (2 * T - 1) + idx] = emb[(size_t)bucket * H + h];
+    }
+}
+
+int forward_impl(s3enc_handle e, const float* const* wav_ptrs_host, const int64_t* lengths, int32_t B, int64_t n_max_in,
+                 float* out, int64_t layer_stride, hipStream_t st) {
+    const s3enc_config& c = e->cfg;
+    const int C = c.conv_dim, D = c.embed_dim, F = c.ffn_dim, H = c.heads, NL = c.encoder_layers;
+    const int dt = e->dtype, es = e->es;
+    if (B <= 0) return fail("s3enc_forward: B must be positive");
+    long n_max = 0;
+    for (int b = 0; b < B; ++b) {
+        if (lengths[b] <= 0) return fail("s3enc_forward: empty utterance");
+        if (lengths[b] > n_max) n_max = lengths[b];
+        if (!wav_ptrs_host[b]) return fail("s3enc_forward: null waveform pointer");
+    }
+    if (n_max_in > 0) {
+        if (n_max_in < n_max) return fail("s3enc_forward: n_max is smaller than the longest utterance");
+        n_max = n_max_in;
+    }
+    std::vector<long> L(c.n_conv);
+    for (int i = 0; i < c.n_conv; ++i) L[i] = conv_len(c, n_max, i + 1);
+    const long T = L[c.n_conv - 1];
+    if (T < 1) return fail("s3enc_forward: input shorter than the receptive field of the conv stack");
+    const long M = (long)B * T;
+    if (layer_stride < M * D) return fail("s3enc_forward: layer_stride < B*T*D");
+    if (!out) return fail("s3enc_forward: null output");
+    std::vector<int> valid(B);
+    for (int b = 0; b < B; ++b) {
+        valid[b] = valid_frames(c, lengths[b], n_max);
+        if (valid[b] < 1) return fail("s3enc_forward: an utterance is too short to produce a valid frame");
+    }
+    HIP_TRY(hipSetDevice(e->device));
+
+    // ---- small device state: tables + stats ----
+    const size_t tbl_bytes = (size_t)B * (8 + 8 + 4);
+    const size_t part_elems = stats_partial_elems(B, n_max);
+    {
+        Bump sb(nullptr);
+        sb.take(tbl_bytes);
+        sb.take((size_t)B * sizeof(float2));
+        sb.take((size_t)B * C * sizeof(float2));
+        sb.take(part_elems * 8);
+        HIP_TRY(e->small.ensure(sb.off + 1024));
+    }
+    Bump sb(e->small.p);
+    char* d_tbl = (char*)sb.take(tbl_bytes);
+    float2* d_norm = (float2*)sb.take((size_t)B * sizeof(float2));
+    float2* d_gn = (float2*)sb.take((size_t)B * C * sizeof(float2));
+    double* d_part = (double*)sb.take(part_elems * 8);
+    const float* const* d_ptrs = (const float* const*)d_tbl;
+    const long* d_lens = (const long*)(d_tbl + (size_t)B * 8);
+    const int* d_valid = (const int*)(d_tbl + (size_t)B * 16);
+
+    // pinned staging ring (so the async H2D copy never reads freed / overwritten host memory)
+    if (tbl_bytes > e->slot_bytes) {
+        HIP_TRY(hipStreamSynchronize(st));
+        if (e->pinned) HIP_TRY(hipHostFree(e->pinned));
+        e->pinned = nullptr;
+        e->slot_bytes = tbl_bytes * 2 + 4096;
+        HIP_TRY(hipHostMalloc(&e->pinned, e->slot_bytes * s3enc_encoder::RING, hipHostMallocDefault));
+    }
+    {
+        const int slot = e->slot_next;
+        e->slot_next = (slot + 1) % s3enc_encoder::RING;
+        HIP_TRY(hipEventSynchronize(e->slot_ev[slot]));
+        char* hp = (char*)e->pinned + (size_t)slot * e->slot_bytes;
+        memcpy(hp, wav_ptrs_host, (size_t)B * 8);
+        for (int b = 0; b < B; ++b) ((long*)(hp + (size_t)B * 8))[b] = (long)lengths[b];
+        memcpy(hp + (size_t)B * 16, valid.data(), (size_t)B * 4);
+        HIP_TRY(hipMemcpyAsync(d_tbl, hp, tbl_bytes, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipEventRecord(e->slot_ev[slot], st));
+    }
+
+    // ---- workspace ----
+    const bool lnmode = c.extractor_layer_norm != 0;
+    const bool prel = c.layer_norm_first != 0;
+    const bool gated = c.rel_pos && c.gru_rel_pos;
+    void *actA, *actB, *tmp32, *feat32, *featT, *x32, *xpc, *xT, *qkv, *attn, *tmp1, *tmp2, *hbuf, *gate;
+    for (int pass = 0; pass < 2; ++pass) {
+        Bump wb(pass ? e->ws.p : nullptr);
+        actA = wb.take((size_t)B * L[0] * C * es);
+        actB = wb.take((size_t)B * L[1] * C * es);
+        tmp32 = lnmode ? wb.take((size_t)B * L[1] * C * 4) : nullptr;
+        feat32 = wb.take((size_t)M * C * 4);
+        featT = wb.take((size_t)M * C * es);
+        x32 = wb.take((size_t)M * D * 4);
+        xpc = wb.take((size_t)M * D * 4);
+        xT = wb.take((size_t)M * D * es);
+        qkv = wb.take((size_t)M * 3 * D * es);
+        attn = wb.take((size_t)M * D * es);
+        tmp1 = wb.take((size_t)M * D * 4);
+        tmp2 = wb.take((size_t)M * D * 4);
+        hbuf = wb.take((size_t)M * F * es);
+        gate = gated ? wb.take((size_t)B * H * T * 4) : nullptr;
+        if (!pass) HIP_TRY(e->ws.ensure(wb.off + 4096));
+    }
+    e->taps.clear();
+
+    WavTable wt{d_ptrs, d_lens, B, n_max};
+    {
+        Prof pr(e, st, "wav_stats", 0, 4.0 * B * n_max);
+        HIP_TRY(launch_wav_norm_stats(wt, c.normalize, d_part, d_norm, st));
+    }
+    if (!lnmode) {
+        Prof pr(e, st, "gn_stats", 0, 4.0 * B * n_max);
+        HIP_TRY(launch_gn_stats(wt, d_norm, (const float*)e->conv[0].w.p, (const float*)e->gn_g.p, (const float*)e->gn_b.p, C,
+                                c.conv_kernel[0], c.conv_stride[0], L[0], d_part, nullptr, d_gn, st));
+    }
+    {
+        Conv0Params p{};
+        p.wav = wt;
+        p.norm = d_norm;
+        p.w0 = (const float*)e->conv[0].w.p;
+        p.bias = e->conv[0].has_bias ? (const float*)e->conv[0].bias.p : nullptr;
+        p.gn = lnmode ? nullptr : d_gn;
+        p.ln_g = lnmode ? (const float*)e->conv[0].lng.p : nullptr;
+        p.ln_b = lnmode ? (const float*)e->conv[0].lnb.p : nullptr;
+        p.C = C;
+        p.k0 = c.conv_kernel[0];
+        p.s0 = c.conv_stride[0];
+        p.L0 = L[0];
+        p.out = actA;
+        Prof pr(e, st, "conv0", 2.0 * B * L[0] * C * p.k0, 4.0 * B * n_max + (double)B * L[0] * C * es);
+        HIP_TRY(launch_conv0(dt, p, st));
+        e->taps["conv0"] = {actA, (long)B * L[0] * C, dt};
+    }
+    // conv1..: implicit GEMM on channel-last activations
+    void* cur = actA;
+    for (int i = 1; i < c.n_conv; ++i) {
+        const bool last = i == c.n_conv - 1;
+        void* dst = last ? feat32 : (cur == actA ? actB : actA);
+        GemmParams g{};
+        g.A = cur;
+        g.lda = (long)c.conv_stride[i] * C;
+        g.a_bs = L[i - 1] * C;
+        g.W = e->conv[i].w.p;
+        g.bias = e->conv[i].has_bias ? (const float*)e->conv[i].bias.p : nullptr;
+        g.M = (int)L[i];
+        g.N = C;
+        g.K = c.conv_kernel[i] * C;
+        g.batches = B;
+        g.ldo = C;
+        g.o_bs = L[i] * C;
+        const double fl = 2.0 * B * L[i] * C * g.K;
+        const double by = ((double)B * L[i - 1] * C + (double)C * g.K) * es + (double)B * L[i] * C * (last ? 4 : es);
+        char kind[32];
+        snprintf(kind, sizeof(kind), "gemm:conv%d", i);
+        if (!lnmode) {
+            g.act = 1;
+            if (last || dt == F32) g.out32 = (float*)dst; else g.out16 = dst;
+            Prof pr(e, st, kind, fl, by);
+            HIP_TRY(launch_gemm(dt, g, st));
+        } else {
+            g.act = 0;
+            g.out32 = (float*)tmp32;
+            {
+                Prof pr(e, st, kind, fl, by);
+                HIP_TRY(launch_gemm(dt, g, st));
+            }
+            Prof pr(e, st, "layernorm:conv", 0, (double)B * L[i] * C * (4 + (last ? 4 : es)));
+            HIP_TRY(launch_layernorm(dt, (const float*)tmp32, (const float*)e->conv[i].lng.p, (const float*)e->conv[i].lnb.p,
+                                     (long)B * L[i], C, 1, (last || dt == F32) ? (float*)dst : nullptr,
+                                     (last || dt == F32) ? nullptr : dst, st));
+        }
+        char tn[16];
+        snprintf(tn, sizeof(tn), "conv%d", i);
+        e->taps[tn] = {dst, (long)B * L[i] * C, last ? F32 : dt};
+        cur = dst;
+    }
+    // LayerNorm(C) -> post_extract_proj (+ zero padded frames)
+    const void* featA;
+    {
+        Prof pr(e, st, "layernorm:feat", 0, (double)M * C * (4 + es));
+        if (dt == F32) {
+            HIP_TRY(launch_layernorm(dt, (const float*)feat32, (const float*)e->fln_g.p, (const float*)e->fln_b.p, M, C, 0,
+                                     (float*)featT, nullptr, st));
+        } else {
+            HIP_TRY(launch_layernorm(dt, (const float*)feat32, (const float*)e->fln_g.p, (const float*)e->fln_b.p, M, C, 0,
+                                     nullptr, featT, st));
+        }
+        featA = featT;
+        e->taps["feat_ln"] = {featT, M * C, dt};
+    }
+    {
+        GemmParams g{};
+        g.A = featA;
+        g.lda = C;
+        g.a_bs = T * C;
+        g.W = e->proj_w.p;
+        g.bias = (const float*)e->proj_b.p;
+        g.M = (int)T;
+        g.N = D;
+        g.K = C;
+        g.batches = B;
+        g.row_limit = d_valid;
+        g.out32 = (float*)x32;
+        g.ldo = D;
+        g.o_bs = T * D;
+        Prof pr(e, st, "gemm:proj", 2.0 * M * D * C, ((double)M * C + (double)D * C) * es + (double)M * D * 4);
+        HIP_TRY(launch_gemm(dt, g, st));
+        e->taps["proj"] = {x32, M * D, F32};
+    }
+    // positional conv + residual; hidden_states[0]
+    float* hs0 = out;
+    {
+        PosConvParams p{};
+        p.x = (const float*)x32;
+        p.w = (const float*)e->pos_w.p;
+        p.bias = (const float*)e->pos_b.p;
+        p.out = prel ? hs0 : (float*)xpc;
+        p.B = B;
+        p.T = (int)T;
+        p.D = D;
+        p.G = c.conv_pos_groups;
+        p.K = c.conv_pos;
+        Prof pr(e, st, "posconv", 2.0 * M * D * (D / p.G) * p.K, (double)M * D * 8 + (double)D * (D / p.G) * p.K * 4);
+        HIP_TRY(launch_posconv(p, st));
+        e->taps["posconv"] = {p.out, M * D, F32};
+    }
+    if (!prel) {
+        Prof pr(e, st, "layernorm:enc", 0, (double)M * D * (8 + (dt == F32 ? 0 : es)));
+        HIP_TRY(launch_layernorm(dt, (const float*)xpc, (const float*)e->eln_g.p, (const float*)e->eln_b.p, M, D, 0, hs0,
+                                 dt == F32 ? nullptr : xT, st));
+    }
+    // WavLM relative-position table for this T
+    const float* d_table = nullptr;
+    if (c.rel_pos) {
+        if (e->rel_table_T != (int)T) {
+            std::vector<float> table;
+            build_rel_table(c, e->rel_emb, (int)T, table);
+            HIP_TRY(hipStreamSynchronize(st));
+            HIP_TRY(upload_f32(e->rel_table, table));
+            e->rel_table_T = (int)T;
+        }
+        d_table = (const float*)e->rel_table.p;
+    }
+
+    const double gM = (double)M;
+    for (int l = 0; l < NL; ++l) {
+        LayerW& Lw = e->layers[l];
+        float* x_in = out + (long)l * layer_stride;         // hidden_states[l] (fp32)
+        float* x_out = out + (long)(l + 1) * layer_stride;  // hidden_states[l+1]
+        const bool lastl = l == NL - 1;
+        const void* a_in;  // operand of the q|k|v GEMM
+        const float* gate_src;  // WavLM: the attention module's input
+        if (prel) {
+            Prof pr(e, st, "layernorm:ln1", 0, gM * D * (4 + es));
+            if (dt == F32) {
+                HIP_TRY(launch_layernorm(dt, x_in, (const float*)Lw.ln1g.p, (const float*)Lw.ln1b.p, M, D, 0, (float*)xT, nullptr, st));
+            } else {
+                HIP_TRY(launch_layernorm(dt, x_in, (const float*)Lw.ln1g.p, (const float*)Lw.ln1b.p, M, D, 0,
+                                         gated ? (float*)tmp2 : nullptr, xT, st));
+            }
+            a_in = xT;
+            gate_src = dt == F32 ? (const float*)xT : (const float*)tmp2;
+        } else {
+            a_in = dt == F32 ? (const void*)x_in : (const void*)xT;
+            gate_src = x_in;
+        }
+        if (gated) {
+            Prof pr(e, st, "wavlm_gate", 2.0 * M * H * 64 * 8, gM * D * 4);
+            HIP_TRY(launch_wavlm_gate(gate_src, (const float*)Lw.grep_w.p, (const float*)Lw.grep_b.p, (const float*)Lw.grep_a.p,
+                                      B, (int)T, H, (float*)gate, st));
+        }
+        {
+            GemmParams g{};
+            g.A = a_in;
+            g.lda = D;
+            g.W = Lw.wqkv.p;
+            g.bias = (const float*)Lw.bqkv.p;
+            g.M = (int)M;
+            g.N = 3 * D;
+            g.K = D;
+            g.batches = 1;
+            g.ldo = 3 * D;
+            if (dt == F32) g.out32 = (float*)qkv; else g.out16 = qkv;
+            Prof pr(e, st, "gemm:qkv", 2.0 * gM * 3 * D * D, (gM * D + 3.0 * D * D + gM * 3 * D) * es);
+            HIP_TRY(launch_gemm(dt, g, st));
+            if (l == 0) e->taps["qkv0"] = {qkv, M * 3 * D, dt};
+        }
+        {
+            AttnParams a{};
+            a.qkv = qkv;
+            a.out = attn;
+            a.valid = d_valid;
+            a.B = B;
+            a.T = (int)T;
+            a.H = H;
+            a.bias_table = d_table;
+            a.gate = gated ? (const float*)gate : nullptr;
+            Prof pr(e, st, "attention", 4.0 * B * H * (double)T * T * 64, gM * 4 * D * es);
+            HIP_TRY(launch_attention(dt, a, st));
+            if (l == 0) e->taps["attn0"] = {attn, M * D, dt};
+        }
+        {   // out_proj + bias + residual
+            GemmParams g{};
+            g.A = attn;
+            g.lda = D;
+            g.W = Lw.wo.p;
+            g.bias = (const float*)Lw.bo.p;
+            g.M = (int)M;
+            g.N = D;
+            g.K = D;
+            g.batches = 1;
+            g.ldo = D;
+            g.residual = x_in;
+            g.out32 = (float*)tmp1;
+            Prof pr(e, st, "gemm:out_proj", 2.0 * gM * D * D, (gM * D + (double)D * D) * es + gM * D * 8);
+            HIP_TRY(launch_gemm(dt, g, st));
+        }
+        const float* ffn_res;
+        const void* ffn_in;
+        if (prel) {  // b = LN2(y) feeds fc1; residual is y itself
+            Prof pr(e, st, "layernorm:ln2", 0, gM * D * (4 + es));
+            HIP_TRY(launch_layernorm(dt, (const float*)tmp1, (const float*)Lw.ln2g.p, (const float*)Lw.ln2b.p, M, D, 0,
+                                     dt == F32 ? (float*)xT : nullptr, dt == F32 ? nullptr : xT, st));
+            ffn_res = (const float*)tmp1;
+            ffn_in = xT;
+        } else {  // x1 = LN1(y): both the fc1 operand and the FFN residual
+            Prof pr(e, st, "layernorm:ln1", 0, gM * D * (8 + (dt == F32 ? 0 : es)));
+            HIP_TRY(launch_layernorm(dt, (const float*)tmp1, (const float*)Lw.ln1g.p, (const float*)Lw.ln1b.p, M, D, 0,
+                                     (float*)tmp2, dt == F32 ? nullptr : xT, st));
+            ffn_res = (const float*)tmp2;
+            ffn_in = dt == F32 ? (const void*)tmp2 : (const void*)xT;
+        }
+        {   // fc1 + bias + GELU
+            GemmParams g{};
+            g.A = ffn_in;
+            g.lda = D;
+            g.W = Lw.w1.p;
+            g.bias = (const float*)Lw.b1.p;
+            g.M = (int)M;
+            g.N = F;
+            g.K = D;
+            g.batches = 1;
+            g.act = 1;
+            g.ldo = F;
+            if (dt == F32) g.out32 = (float*)hbuf; else g.out16 = hbuf;
+            Prof pr(e, st, "gemm:fc1", 2.0 * gM * F * D, (gM * D + (double)F * D + gM * F) * es);
+            HIP_TRY(launch_gemm(dt, g, st));
+        }
+        {   // fc2 + bias + residual
+            GemmParams g{};
+            g.A = hbuf;
+            g.lda = F;
+            g.W = Lw.w2.p;
+            g.bias = (const float*)Lw.b2.p;
+            g.M = (int)M;
+            g.N = D;
+            g.K = F;
+            g.batches = 1;
+            g.ldo = D;
+            g.residual = ffn_res;
+            // pre-LN: the raw residual stream IS hidden_states[l+1] (except after the last layer, which is normed)
+            g.out32 = prel ? (lastl ? (float*)tmp2 : x_out) : (float*)tmp1;
+            Prof pr(e, st, "gemm:fc2", 2.0 * gM * D * F, (gM * F + (double)D * F) * es + gM * D * 8);
+            HIP_TRY(launch_gemm(dt, g, st));
+        }
+        if (!prel) {
+            Prof pr(e, st, "layernorm:ln2", 0, gM * D * (8 + (dt == F32 ? 0 : es)));
+            HIP_TRY(launch_layernorm(dt, (const float*)tmp1, (const float*)Lw.ln2g.p, (const float*)Lw.ln2b.p, M, D, 0, x_out,
+                                     (dt == F32 || lastl) ? nullptr : xT, st));
+        } else if (lastl) {
+            Prof pr(e, st, "layernorm:enc", 0, gM * D * 8);
+            HIP_TRY(launch_layernorm(dt, (const float*)tmp2, (const float*)e->eln_g.p, (const float*)e->eln_b.p, M, D, 0, x_out,
+                                     nullptr, st));
+        }
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int s3enc_forward(s3enc_handle h, const float* const* wavs, const int64_t* lengths, int32_t B, int64_t n_max, float* out,
+                  int64_t layer_stride, void* stream) {
+    if (!h || !wavs || !lengths) return fail("s3enc_forward: null argument");
+    return forward_impl(h, wavs, lengths, B, n_max, out, layer_stride, (hipStream_t)stream);
+}
+
+int s3enc_forward_padded(s3enc_handle h, const float* pcm, int64_t row_stride, const int64_t* lengths, int32_t B, int64_t n_max,
+                         float* out, int64_t layer_stride, void* stream) {
+    if (!h || !pcm || !lengths) return fail("s3enc_forward_padded: null argument");
+    if (B <= 0) return fail("s3enc_forward_padded: B must be positive");
+    std::vector<const float*> ptrs(B);
+    for (int b = 0; b < B; ++b) {
+        if (lengths[b] > row_stride) return fail("s3enc_forward_padded: length exceeds row_stride");
+        ptrs[b] = pcm + (long)b * row_stride;
+    }
+    return forward_impl(h, ptrs.data(), lengths, B, n_max, out, layer_stride, (hipStream_t)stream);
+}
+
+int s3enc_profile_enable(s3enc_handle h, int32_t on) {
+    if (!h) return fail("null handle");
+    h->prof = on != 0;
+    return 0;
+}
+int s3enc_profile_reset(s3enc_handle h) {
+    if (!h) return fail("null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());
+    for (auto& r : h->recs) {
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    h->recs.clear();
+    h->kinds.clear();
+    h->kflops.clear();
+    h->kbytes.clear();
+    h->klaunches.clear();
+    return 0;
+}
+int s3enc_profile_read(s3enc_handle h, s3enc_profile_entry* entries, int32_t max_entries, int32_t* n_entries) {
+    if (!h || !entries || !n_entries) return fail("s3enc_profile_read: null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());
+    std::vector<double> ms(h->kinds.size(), 0.0);
+    for (auto& r : h->recs) {
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, r.a, r.b));
+        ms[r.kind] += t;
+    }
+    int n = 0;
+    for (size_t k = 0; k < h->kinds.size() && n < max_entries; ++k, ++n) {
+        memset(&entries[n], 0, sizeof(entries[n]));
+        strncpy(entries[n].name, h->kinds[k].c_str(), sizeof(entries[n].name) - 1);
+        entries[n].launches = h->klaunches[k];
+        entries[n].ms = ms[k];
+        entries[n].flops = h->kflops[k];
+        entries[n].bytes = h->kbytes[k];
+    }
+    *n_entries = n;
+    return 0;
+}
+
+int s3enc_debug_tap(s3enc_handle h, const char* name, float* host_out, int64_t max_elems, int64_t* n_elems) {
+    if (!h || !name || !n_elems) return fail("s3enc_debug_tap: null argument");
+    auto it = h->taps.find(name);
+    if (it == h->taps.end()) return fail(std::string("s3enc_debug_tap: unknown tap '") + name + "'");
+    *n_elems = it->second.elems;
+    if (!host_out) return 0;
+    if (max_elems < it->second.elems) return fail("s3enc_debug_tap: buffer too small");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());
+    if (it->second.dtype == F32) {
+        HIP_TRY(hipMemcpy(host_out, it->second.p, (size_t)it->second.elems * 4, hipMemcpyDeviceToHost));
+    } else {
+        std::vector<uint16_t> tmp((size_t)it->second.elems);
+        HIP_TRY(hipMemcpy(tmp.data(), it->second.p, tmp.size() * 2, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < tmp.size(); ++i) host_out[i] = h_from16(tmp[i], it->second.dtype);
+    }
+    return 0;
+}
+
+// ---- single-kernel entry points -------------------------------------------------------------------------------
+int s3enc_op_gemm(int32_t dtype, const void* A, int64_t lda, int64_t a_batch_stride, const void* W, const float* bias, int32_t M,
+                  int32_t N, int32_t K, int32_t batches, int32_t act, const float* residual, const int32_t* row_limit,
+                  float* out32, void* out16, int64_t ldo, int64_t o_batch_stride, void* stream) {
+    GemmParams g{};
+    g.A = A;
+    g.lda = lda;
+    g.a_bs = a_batch_stride;
+    g.W = W;
+    g.bias = bias;
+    g.M = M;
+    g.N = N;
+    g.K = K;
+    g.batches = batches;
+    g.act = act;
+    g.residual = residual;
+    g.row_limit = row_limit;
+    g.out32 = out32;
+    g.out16 = out16;
+    g.ldo = ldo;
+    g.o_bs = o_batch_stride;
+    HIP_TRY(launch_gemm(dtype, g, (hipStream_t)stream));
+    return 0;
+}
+
+int s3enc_op_layernorm(int32_t dtype, const float* x, const float* gamma, const float* beta, int32_t rows, int32_t C, int32_t act,
+                       float* out32, void* out16, void* stream) {
+    HIP_TRY(launch_layernorm(dtype, x, gamma, beta, rows, C, act, out32, out16, (hipStream_t)stream));
+    return 0;
+}
+
+int s3enc_op_attention(int32_t dtype, const void* qkv, void* out, const int32_t* valid, int32_t B, int32_t T, int32_t H,
+                       const float* bias_table, const float* gate, void* stream) {
+    AttnParams a{};
+    a.qkv = qkv;
+    a.out = out;
+    a.valid = valid;
+    a.B = B;
+    a.T = T;
+    a.H = H;
+    a.bias_table = bias_table;
+    a.gate = gate;
+    HIP_TRY(launch_attention(dtype, a, (hipStream_t)stream));
+    return 0;
+}
+
+}  // extern "C"

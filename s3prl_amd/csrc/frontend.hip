@@ -1,0 +1,296 @@
+// frontend.hip — raw 16 kHz PCM -> first conv layer activations.  HBM/VALU-bound.
+//
+//  * wav_norm_stats : per-utterance mean / rstd for task_cfg.normalize  (F.layer_norm(wav, wav.shape),
+//                     hubert/expert.py:57-58) — applied on load by the consumers, never materialised.
+//  * gn_stats       : Fp32GroupNorm(C, C) statistics of conv0's output (wav2vec2_model.py:2902,1841-1853)
+//                     WITHOUT computing conv0: conv0 is linear in the waveform, so with
+//                     S[j] = sum_t x[s*t+j] and R[j][j'] = sum_t x[s*t+j] x[s*t+j'] (k0 + k0^2 numbers per
+//                     utterance, accumulated in fp64 over all L0 frames incl. the zero padding):
+//                       mean_c = w_c.S / L0,   E[y^2]_c = w_c^T R w_c / L0.
+//                     One pass over 4 B/sample of PCM instead of a pass over the 512-channel activation.
+//  * conv0          : Conv1d(1, C, k=10, s=5) + {GroupNorm affine | LayerNorm over C} + erf-GELU, one wave per
+//                     output frame, lanes across channels (coalesced 1 KiB row stores, LayerNorm statistics by
+//                     wavefront shuffles), the PCM window of a 64-frame tile staged once in LDS and broadcast.
+//                     Output is channel-last (B, L0, C) in the compute dtype, which makes conv1..6 plain
+//                     strided-row GEMMs (gemm.hip).
+// Padding (pad_sequence + wav mask, hubert/expert.py:60-66) is never built: reads past lens[b] return 0.
+#include "kernels.h"
+
+namespace s3 {
+
+namespace {
+
+constexpr int STAT_CHUNK = 16384;  // samples per block of wav_norm_stats
+constexpr int GN_FRAMES = 4096;    // frames per block of gn_stats
+constexpr int ROWLEN = 1 + STAT_K0_MAX;
+
+__device__ __forceinline__ float load_wav(const float* w, long len, long i, float mean, float rstd) {
+    return i < len ? (w[i] - mean) * rstd : 0.f;
+}
+
+__device__ __forceinline__ double block_sum_d(double v, double* red /*[4]*/) {
+    v = wave_sum_d(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void wav_sum_kernel(WavTable w, double* partial, int chunks) {
+    __shared__ double red[4];
+    const int b = blockIdx.y, ch = blockIdx.x;
+    const float* x = w.ptrs[b];
+    const long len = w.lens[b];
+    const long beg = (long)ch * STAT_CHUNK;
+    long end = beg + STAT_CHUNK;
+    end = end < len ? end : len;
+    double s = 0, s2 = 0;
+    for (long i = beg + threadIdx.x; i < end; i += 256) {
+        const double v = x[i];
+        s += v;
+        s2 += v * v;
+    }
+    s = block_sum_d(s, red);
+    s2 = block_sum_d(s2, red);
+    if (threadIdx.x == 0) {
+        partial[((long)b * chunks + ch) * 2 + 0] = s;
+        partial[((long)b * chunks + ch) * 2 + 1] = s2;
+    }
+}
+
+__global__ void wav_norm_final_kernel(WavTable w, const double* partial, int chunks, int normalize, float2* norm) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= w.B) return;
+    if (!normalize) {
+        norm[b] = make_float2(0.f, 1.f);
+        return;
+    }
+    double s = 0, s2 = 0;
+    for (int c = 0; c < chunks; ++c) {  // fixed order: run-to-run deterministic
+        s += partial[((long)b * chunks + c) * 2 + 0];
+        s2 += partial[((long)b * chunks + c) * 2 + 1];
+    }
+    const double n = (double)w.lens[b];
+    const double mean = s / n;
+    double var = s2 / n - mean * mean;  // biased, like F.layer_norm
+    var = var > 0 ? var : 0;
+    norm[b] = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)LN_EPS)));
+}
+
+// partial[b][chunk][j][0] = sum_t x[s0 t + j];  [1+jj] = sum_t x[s0 t + j] x[s0 t + jj]
+__global__ __launch_bounds__(256) void gn_lag_kernel(WavTable w, const float2* norm, int k0, int s0, long L0, double* partial,
+                                                     int chunks) {
+    __shared__ double red[4];
+    const int ch = blockIdx.x, b = blockIdx.y, j = blockIdx.z;
+    const float* x = w.ptrs[b];
+    const long len = w.lens[b];
+    const float mean = norm[b].x, rstd = norm[b].y;
+    const long t_beg = (long)ch * GN_FRAMES;
+    long t_end = t_beg + GN_FRAMES;
+    t_end = t_end < L0 ? t_end : L0;
+    double acc[ROWLEN];
+#pragma unroll
+    for (int e = 0; e < ROWLEN; ++e) acc[e] = 0;
+    for (long t = t_beg + threadIdx.x; t < t_end; t += 256) {
+        const long base = t * s0;
+        const double xj = load_wav(x, len, base + j, mean, rstd);
+        acc[0] += xj;
+#pragma unroll
+        for (int jj = 0; jj < STAT_K0_MAX; ++jj)
+            if (jj < k0) acc[1 + jj] += xj * (double)load_wav(x, len, base + jj, mean, rstd);
+    }
+    double* dst = partial + (((long)b * chunks + ch) * k0 + j) * ROWLEN;
+#pragma unroll
+    for (int e = 0; e < ROWLEN; ++e) {
+        const double v = block_sum_d(acc[e], red);
+        if (threadIdx.x == 0) dst[e] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_final_kernel(const double* partial, int chunks, int k0, long L0, const float* w0,
+                                                       const float* gamma, const float* beta, int C, float2* gn) {
+    __shared__ double sums[STAT_K0_MAX * ROWLEN];
+    const int b = blockIdx.x;
+    for (int e = threadIdx.x; e < k0 * ROWLEN; e += 256) {
+        double s = 0;
+        for (int c = 0; c < chunks; ++c) s += partial[((long)b * chunks + c) * k0 * ROWLEN + e];
+        sums[e] = s;
+    }
+    __syncthreads();
+    const double inv = 1.0 / (double)L0;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        double m = 0, e2 = 0;
+        for (int j = 0; j < k0; ++j) {
+            const double wj = w0[c * k0 + j];
+            m += wj * sums[j * ROWLEN];
+            double r = 0;
+            for (int jj = 0; jj < k0; ++jj) r += (double)w0[c * k0 + jj] * sums[j * ROWLEN + 1 + jj];
+            e2 += wj * r;
+        }
+        m *= inv;
+        e2 *= inv;
+        double var = e2 - m * m;  // conv bias shifts the mean only, so it cancels in (y - mean)
+        var = var > 0 ? var : 0;
+        const double scale = (double)gamma[c] / sqrt(var + (double)LN_EPS);
+        gn[(long)b * C + c] = make_float2((float)scale, (float)((double)beta[c] - m * scale));
+    }
+}
+
+// ---- conv0 -------------------------------------------------------------------------------------------------
+constexpr int C0_FT = 64;  // frames per block
+
+template <typename T, int NG, int K0>
+__global__ __launch_bounds__(256) void conv0_kernel(Conv0Params p) {
+    typedef typename Cvt<T>::store_t store_t;
+    __shared__ float xs[(C0_FT - 1) * 8 + STAT_K0_MAX];  // stride <= 8 supported
+    const int b = blockIdx.y;
+    const long t0 = (long)blockIdx.x * C0_FT;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* x = p.wav.ptrs[b];
+    const long len = p.wav.lens[b];
+    const float mean = p.norm[b].x, rstd = p.norm[b].y;
+    const int nwin = (C0_FT - 1) * p.s0 + K0;
+    for (int i = threadIdx.x; i < nwin; i += 256) xs[i] = load_wav(x, len, t0 * p.s0 + i, mean, rstd);
+
+    // per-lane constants: channels 4*(lane+64g) .. +3
+    float w[NG][4][K0];
+    float a0[NG][4], a1[NG][4];  // GN: scale, shift;  LN: gamma, beta
+    float cb[NG][4];
+    bool act[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int c0 = 4 * (lane + 64 * g);
+        act[g] = c0 < p.C;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = act[g] ? c0 + u : 0;
+#pragma unroll
+            for (int j = 0; j < K0; ++j) w[g][u][j] = act[g] ? p.w0[c * K0 + j] : 0.f;
+            cb[g][u] = (act[g] && p.bias) ? p.bias[c] : 0.f;
+            if (p.gn) {
+                const float2 ss = p.gn[(long)b * p.C + c];
+                a0[g][u] = ss.x;
+                a1[g][u] = ss.y;
+            } else {
+                a0[g][u] = p.ln_g[c];
+                a1[g][u] = p.ln_b[c];
+            }
+        }
+    }
+    __syncthreads();
+
+    const float invC = 1.f / (float)p.C;
+    for (int f = wave; f < C0_FT; f += 4) {
+        const long t = t0 + f;
+        if (t >= p.L0) break;
+        float xv[K0];
+#pragma unroll
+        for (int j = 0; j < K0; ++j) xv[j] = xs[f * p.s0 + j];
+        float v[NG][4];
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float s = 0.f;
+#pragma unroll
+                for (int j = 0; j < K0; ++j) s = fmaf(w[g][u][j], xv[j], s);
+                v[g][u] = s;
+            }
+        if (p.gn) {
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[g][u] = gelu_erf(fmaf(v[g][u], a0[g][u], a1[g][u]));
+        } else {
+            // Fp32LayerNorm over the C channels of this frame (wav2vec2_model.py:2887-2897), two-pass
+            float s = 0.f;
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    v[g][u] += cb[g][u];
+                    s += act[g] ? v[g][u] : 0.f;
+                }
+            const float mu = wave_sum(s) * invC;
+            float q = 0.f;
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float d = v[g][u] - mu;
+                    q += act[g] ? d * d : 0.f;
+                }
+            const float rs = rsqrtf(wave_sum(q) * invC + LN_EPS);
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[g][u] = gelu_erf((v[g][u] - mu) * rs * a0[g][u] + a1[g][u]);
+        }
+        store_t* o = (store_t*)p.out + ((long)b * p.L0 + t) * p.C;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (!act[g]) continue;
+            const int c0 = 4 * (lane + 64 * g);
+            if constexpr (sizeof(store_t) == 4) {
+                *(float4*)(o + c0) = make_float4(v[g][0], v[g][1], v[g][2], v[g][3]);
+            } else {
+                ushort4 h;
+                h.x = Cvt<T>::to(v[g][0]);
+                h.y = Cvt<T>::to(v[g][1]);
+                h.z = Cvt<T>::to(v[g][2]);
+                h.w = Cvt<T>::to(v[g][3]);
+                *(ushort4*)(o + c0) = h;
+            }
+        }
+    }
+}
+
+template <typename T>
+hipError_t conv0_dispatch(const Conv0Params& p, hipStream_t s) {
+    dim3 grid((unsigned)((p.L0 + C0_FT - 1) / C0_FT), p.wav.B);
+    const int ng = (p.C + 255) / 256;
+    if (ng <= 1)
+        hipLaunchKernelGGL((conv0_kernel<T, 1, 10>), grid, dim3(256), 0, s, p);
+    else if (ng == 2)
+        hipLaunchKernelGGL((conv0_kernel<T, 2, 10>), grid, dim3(256), 0, s, p);
+    else
+        hipLaunchKernelGGL((conv0_kernel<T, 4, 10>), grid, dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+size_t stats_partial_elems(int B, long n_max) {
+    const size_t c1 = (size_t)((n_max + STAT_CHUNK - 1) / STAT_CHUNK) * 2;
+    const size_t c2 = (size_t)((n_max / 1 + GN_FRAMES - 1) / GN_FRAMES) * STAT_K0_MAX * ROWLEN;
+    return (size_t)B * (c1 > c2 ? c1 : c2);
+}
+
+hipError_t launch_wav_norm_stats(const WavTable& w, int normalize, double* partial, float2* norm, hipStream_t s) {
+    const int chunks = (int)((w.n_max + STAT_CHUNK - 1) / STAT_CHUNK);
+    if (normalize) hipLaunchKernelGGL(wav_sum_kernel, dim3(chunks, w.B), dim3(256), 0, s, w, partial, chunks);
+    hipLaunchKernelGGL(wav_norm_final_kernel, dim3((w.B + 63) / 64), dim3(64), 0, s, w, partial, chunks, normalize, norm);
+    return hipGetLastError();
+}
+
+hipError_t launch_gn_stats(const WavTable& w, const float2* norm, const float* w0, const float* gamma, const float* beta,
+                           int C, int k0, int s0, long L0, double* partial, double* /*sums*/, float2* gn, hipStream_t s) {
+    if (k0 > STAT_K0_MAX) return hipErrorInvalidValue;
+    const int chunks = (int)((L0 + GN_FRAMES - 1) / GN_FRAMES);
+    hipLaunchKernelGGL(gn_lag_kernel, dim3(chunks, w.B, k0), dim3(256), 0, s, w, norm, k0, s0, L0, partial, chunks);
+    hipLaunchKernelGGL(gn_final_kernel, dim3(w.B), dim3(256), 0, s, partial, chunks, k0, L0, w0, gamma, beta, C, gn);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv0(int dtype, const Conv0Params& p, hipStream_t s) {
+    // the kernel is specialised for the first layer every released checkpoint has: k = 10, stride <= 8, C <= 1024
+    if (p.k0 != 10 || p.s0 > 8 || p.s0 < 1 || p.C > 1024 || (p.C & 3)) return hipErrorInvalidValue;
+    switch (dtype) {
+        case F32: return conv0_dispatch<float>(p, s);
+        case BF16: return conv0_dispatch<bf16_tag>(p, s);
+        case F16: return conv0_dispatch<f16_tag>(p, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace s3

@@ -1,0 +1,82 @@
+// kernels.h — host-side launch interface of the HIP kernels (internal to libs3enc).
+#pragma once
+#include "common.h"
+
+namespace s3 {
+
+// ---- gemm.hip -----------------------------------------------------------------------------------------
+struct GemmParams {
+    const void* A;  // (batches, M, K) rows at A + b*a_bs + m*lda (elements of the compute dtype)
+    long lda, a_bs;
+    const void* W;  // (N, K) row-major, compute dtype
+    const float* bias;
+    int M, N, K, batches;
+    int act;                // 0 none, 1 erf-GELU
+    const float* residual;  // fp32, indexed like out32; added after the activation
+    const int* row_limit;   // per batch: rows >= row_limit[b] are written as 0
+    float* out32;
+    void* out16;
+    long ldo, o_bs;
+};
+hipError_t launch_gemm(int dtype, const GemmParams& p, hipStream_t stream);
+
+// ---- frontend.hip ---------------------------------------------------------------------------------------
+// Waveform table: wav b is `ptrs[b]` with `lens[b]` valid samples; reads beyond are zeros (the padding).
+struct WavTable {
+    const float* const* ptrs;  // device array [B]
+    const long* lens;          // device array [B]
+    int B;
+    long n_max;
+};
+constexpr int STAT_K0_MAX = 16;  // conv0 kernel width limit for the closed-form GroupNorm statistics
+// per-utterance mean / rstd of the raw waveform (task_cfg.normalize); norm[b] = {mean, rstd}; identity if !normalize
+hipError_t launch_wav_norm_stats(const WavTable& w, int normalize, double* partial, float2* norm, hipStream_t s);
+// GroupNorm(C,C) statistics of conv0's output from the k0 + k0*(k0+1)/2 lag sums of the waveform, then the
+// fused per-(b,c) affine:  gn[b][c] = {scale, shift} with  y = conv0_raw * scale + shift
+hipError_t launch_gn_stats(const WavTable& w, const float2* norm, const float* w0 /*[C][k0]*/, const float* gamma,
+                           const float* beta, int C, int k0, int s0, long L0, double* partial, double* sums,
+                           float2* gn, hipStream_t s);
+size_t stats_partial_elems(int B, long n_max);  // doubles needed for `partial`
+struct Conv0Params {
+    WavTable wav;
+    const float2* norm;   // [B] {mean, rstd}
+    const float* w0;      // [C][k0]
+    const float* bias;    // [C] or null
+    const float2* gn;     // [B][C] {scale, shift} (GroupNorm mode) or null
+    const float* ln_g;    // [C] (layer_norm mode) or null
+    const float* ln_b;
+    int C, k0, s0;
+    long L0;
+    void* out;            // (B, L0, C) compute dtype
+};
+hipError_t launch_conv0(int dtype, const Conv0Params& p, hipStream_t s);
+
+// ---- norm.hip -------------------------------------------------------------------------------------------
+hipError_t launch_layernorm(int dtype, const float* x, const float* gamma, const float* beta, long rows, int C, int act,
+                            float* out32, void* out16, hipStream_t s);
+
+// ---- attention.hip ----------------------------------------------------------------------------------------
+struct AttnParams {
+    const void* qkv;  // (B*T, 3D): q | k | v, q already scaled by head_dim^-0.5
+    void* out;        // (B*T, D)
+    const int* valid; // [B] keys >= valid[b] are masked
+    int B, T, H;
+    const float* bias_table;  // WavLM: [H][2T-1] or null
+    const float* gate;        // WavLM: [B][H][T] or null (then gate = 1)
+};
+hipError_t launch_attention(int dtype, const AttnParams& p, hipStream_t s);
+// WavLM gate (wavlm/modules.py:535-549) from the layer input x (fp32 rows of D): gate[b][h][t]
+hipError_t launch_wavlm_gate(const float* x, const float* grep_w /*[8][64]*/, const float* grep_b /*[8]*/,
+                             const float* grep_a /*[H]*/, int B, int T, int H, float* gate, hipStream_t s);
+
+// ---- posconv.hip --------------------------------------------------------------------------------------------
+struct PosConvParams {
+    const float* x;     // (B, T, D) fp32, padded frames already zero
+    const float* w;     // packed [G][K][Dg/16][Dg(n)][16]
+    const float* bias;  // [D]
+    float* out;         // (B, T, D) fp32 = x + gelu(conv(x) + bias)
+    int B, T, D, G, K;
+};
+hipError_t launch_posconv(const PosConvParams& p, hipStream_t s);
+
+}  // namespace s3

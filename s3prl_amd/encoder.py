@@ -1,0 +1,132 @@
+"""Host-side handle on the HIP encoder: owns a ``s3enc_handle``; torch is used only for device memory
+(outputs are torch-allocated so the caller owns them, SURVEY §8b "Ownership") and for the current stream."""
+
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from .config import EncoderConfig
+
+
+class HipEncoder:
+    """wav2vec2 / HuBERT / WavLM encoder forward on one MI355X through ``libs3enc.so``."""
+
+    def __init__(self, cfg: EncoderConfig, weights: Dict[str, "np.ndarray"], dtype: str = "fp32",
+                 device: Optional[int] = None):
+        import torch
+
+        cfg.validate()
+        self.cfg = cfg
+        self.dtype = dtype
+        self._lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.S3EncError("no GPU visible: the s3prl_amd encoder has no CPU fallback (use the reference s3prl on CPU)")
+        self.device = torch.cuda.current_device() if device is None else int(device)
+        ccfg = _lib.make_config(cfg, dtype)
+        keep = []
+        tensors = (_lib.S3Tensor * len(weights))()
+        for i, (name, w) in enumerate(weights.items()):
+            if hasattr(w, "detach"):
+                w = w.detach().cpu().float().numpy()
+            a = np.ascontiguousarray(w, dtype=np.float32)
+            keep.append(a)
+            tensors[i].name = name.encode()
+            tensors[i].data = a.ctypes.data_as(C.POINTER(C.c_float))
+            tensors[i].ndim = min(a.ndim, 4)
+            shape = list(a.shape) if a.ndim <= 4 else [int(np.prod(a.shape[:-3]))] + list(a.shape[-3:])
+            for j, s in enumerate(shape):
+                tensors[i].shape[j] = int(s)
+        h = C.c_void_p()
+        _lib.check(self._lib.s3enc_create(C.byref(ccfg), tensors, len(weights), self.device, C.byref(h)), "s3enc_create")
+        self._h = h
+        self.num_layers = cfg.encoder_layers
+        self.embed_dim = cfg.encoder_embed_dim
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.s3enc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- shape helpers (answered by the library so host and device agree) ----
+    def num_frames(self, n: int) -> int:
+        t = C.c_int32()
+        _lib.check(self._lib.s3enc_num_frames(self._h, int(n), C.byref(t)))
+        return t.value
+
+    def valid_frames(self, length: int, n_max: int) -> int:
+        v = C.c_int32()
+        _lib.check(self._lib.s3enc_valid_frames(self._h, int(length), int(n_max), C.byref(v)))
+        return v.value
+
+    def downsample_rate(self) -> int:
+        r = C.c_int32()
+        _lib.check(self._lib.s3enc_downsample_rate(self._h, C.byref(r)))
+        return r.value
+
+    # ---- forward ----
+    def forward(self, wavs: Sequence["torch.Tensor"], n_max: Optional[int] = None, out: Optional["torch.Tensor"] = None):
+        """wavs: list of 1-D fp32 CUDA tensors.  Returns a (NL+1, B, T, D) fp32 CUDA tensor; ``[l]`` is
+        ``hidden_states[l]``.  ``n_max``: pad-to length of the GLOBAL batch (data-parallel shards)."""
+        import torch
+
+        B = len(wavs)
+        if B == 0:
+            raise ValueError("empty batch")
+        dev = torch.device("cuda", self.device)
+        held = []
+        for w in wavs:
+            if w.dim() != 1:
+                raise ValueError("each wav must be a 1-D tensor of samples")
+            if w.device != dev or w.dtype != torch.float32 or not w.is_contiguous():
+                w = w.to(device=dev, dtype=torch.float32).contiguous()
+            held.append(w)
+        lengths = [int(w.numel()) for w in held]
+        nm = max(lengths) if n_max is None else int(n_max)
+        T = self.num_frames(nm)
+        if T < 1:
+            raise ValueError(f"input of {nm} samples is shorter than the receptive field of the conv stack")
+        NL, D = self.num_layers, self.embed_dim
+        if out is None:
+            out = torch.empty((NL + 1, B, T, D), dtype=torch.float32, device=dev)
+        else:
+            assert out.is_contiguous() and out.dtype == torch.float32 and tuple(out.shape) == (NL + 1, B, T, D)
+        ptrs = (C.c_void_p * B)(*[w.data_ptr() for w in held])
+        lens = (C.c_int64 * B)(*lengths)
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            rc = self._lib.s3enc_forward(self._h, ptrs, lens, B, nm, C.c_void_p(out.data_ptr()), B * T * D,
+                                         C.c_void_p(stream))
+        _lib.check(rc, "s3enc_forward")
+        return out
+
+    # ---- measurement / test hooks ----
+    def profile_enable(self, on: bool = True):
+        _lib.check(self._lib.s3enc_profile_enable(self._h, int(on)))
+
+    def profile_reset(self):
+        _lib.check(self._lib.s3enc_profile_reset(self._h))
+
+    def profile_read(self) -> List[dict]:
+        n = C.c_int32()
+        ents = (_lib.S3ProfileEntry * 128)()
+        _lib.check(self._lib.s3enc_profile_read(self._h, ents, 128, C.byref(n)))
+        return [dict(name=ents[i].name.decode(), launches=int(ents[i].launches), ms=float(ents[i].ms),
+                     flops=float(ents[i].flops), bytes=float(ents[i].bytes)) for i in range(n.value)]
+
+    def debug_tap(self, name: str) -> "np.ndarray":
+        n = C.c_int64()
+        _lib.check(self._lib.s3enc_debug_tap(self._h, name.encode(), None, 0, C.byref(n)))
+        buf = np.empty(n.value, dtype=np.float32)
+        _lib.check(self._lib.s3enc_debug_tap(self._h, name.encode(), buf.ctypes.data_as(C.POINTER(C.c_float)), n.value,
+                                             C.byref(n)))
+        return buf

@@ -1,0 +1,191 @@
+"""Per-kernel parity tests on the GPU, through the C ABI (s3enc_op_*), against float64 numpy restatements."""
+
+import ctypes as C
+import zlib
+
+import numpy as np
+import pytest
+
+from oracle import encoder_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"fp32": 2e-5, "bf16": 1.2e-2, "fp16": 2e-3}
+
+
+def _torch():
+    import torch
+
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch
+
+
+def _round(x, dtype):
+    """Round an fp32 numpy array to the 16-bit operand type (what the kernels see)."""
+    torch = _torch()
+    if dtype == "fp32":
+        return x.astype(np.float32)
+    t = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
+    t = t.to(torch.bfloat16 if dtype == "bf16" else torch.float16)
+    return t.float().numpy()
+
+
+def _dev(x, dtype="fp32"):
+    torch = _torch()
+    t = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).cuda()
+    if dtype == "bf16":
+        t = t.to(torch.bfloat16)
+    elif dtype == "fp16":
+        t = t.to(torch.float16)
+    return t.contiguous()
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
+@pytest.mark.parametrize("case", ["plain", "conv", "epilogue", "edge"])
+def test_gemm(dtype, case):
+    torch = _torch()
+    from s3prl_amd import _lib
+
+    lib = _lib.load()
+    rng = np.random.default_rng(zlib.crc32(f"{dtype}/{case}".encode()))
+    act, use_res, use_lim = 0, False, False
+    if case == "plain":
+        batches, M, N, K, lda = 1, 300, 384, 256, 256
+    elif case == "conv":  # Conv1d(C, C, k=3, s=2) on channel-last rows: lda = 2C < K = 3C
+        Cc, Lin = 64, 301
+        M = (Lin - 3) // 2 + 1
+        batches, N, K, lda = 3, 64, 3 * Cc, 2 * Cc
+        act = 1
+    elif case == "epilogue":
+        batches, M, N, K, lda = 2, 130, 136, 128, 128
+        act, use_res, use_lim = 1, True, True
+    else:  # ragged everything: M, N not multiples of the tile, K with a partial 128-byte stage
+        batches, M, N, K, lda = 2, 77, 72, 200, 200
+    if case == "conv":
+        a_bs = Lin * Cc
+        A = rng.standard_normal((batches, Lin * Cc)).astype(np.float32)
+    else:
+        a_bs = M * lda
+        A = rng.standard_normal((batches, M * lda)).astype(np.float32)
+    W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    res = rng.standard_normal((batches, M, N)).astype(np.float32)
+    lim = np.array([M - 5, M // 2, M][:batches] + [M] * max(0, batches - 3), dtype=np.int32)[:batches]
+
+    Ar, Wr = _round(A, dtype).astype(np.float64), _round(W, dtype).astype(np.float64)
+    ref = np.empty((batches, M, N))
+    for b in range(batches):
+        rows = np.stack([Ar[b, m * lda:m * lda + K] for m in range(M)])
+        y = rows @ Wr.T + bias
+        if act:
+            y = O.gelu(y)
+        if use_res:
+            y = y + res[b]
+        if use_lim:
+            y[lim[b]:] = 0
+        ref[b] = y
+
+    dA, dW = _dev(A, dtype), _dev(W, dtype)
+    dbias, dres, dlim = _dev(bias), _dev(res), torch.from_numpy(lim).cuda()
+    out32 = torch.full((batches, M, N), float("nan"), device="cuda")
+    out16 = None
+    if dtype != "fp32":
+        out16 = torch.zeros((batches, M, N), device="cuda", dtype=torch.bfloat16 if dtype == "bf16" else torch.float16)
+    rc = lib.s3enc_op_gemm(_lib.DTYPES[dtype], _ptr(dA), lda, a_bs, _ptr(dW), _ptr(dbias), M, N, K, batches, act,
+                           _ptr(dres) if use_res else None, _ptr(dlim) if use_lim else None, _ptr(out32), _ptr(out16),
+                           N, M * N, None)
+    _lib.check(rc, "s3enc_op_gemm")
+    torch.cuda.synchronize()
+    got = out32.cpu().numpy()
+    assert np.isfinite(got).all()
+    err = O.rel_err(got, ref)
+    assert err < TOL[dtype], f"gemm {dtype}/{case}: rel-err {err:.3e}"
+    # element-wise check catches a transposed / permuted tile that a norm would also catch but names the spot
+    bad = np.abs(got - ref) > 50 * TOL[dtype] * (1 + np.abs(ref))
+    assert not bad.any(), f"{bad.sum()} elements off, first at {np.argwhere(bad)[0]}"
+    if out16 is not None:
+        assert O.rel_err(out16.float().cpu().numpy(), ref) < 2 * TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("C_", [64, 512, 768, 1024])
+def test_layernorm(dtype, C_):
+    torch = _torch()
+    from s3prl_amd import _lib
+
+    lib = _lib.load()
+    rng = np.random.default_rng(C_)
+    rows = 37
+    x = (rng.standard_normal((rows, C_)) * 3 + 1.5).astype(np.float32)
+    g = (1 + 0.2 * rng.standard_normal(C_)).astype(np.float32)
+    b = (0.3 * rng.standard_normal(C_)).astype(np.float32)
+    for act in (0, 1):
+        ref = O.layer_norm(x.astype(np.float64), g.astype(np.float64), b.astype(np.float64))
+        if act:
+            ref = O.gelu(ref)
+        out32 = torch.empty((rows, C_), device="cuda")
+        out16 = torch.empty((rows, C_), device="cuda", dtype=torch.bfloat16) if dtype == "bf16" else None
+        rc = lib.s3enc_op_layernorm(_lib.DTYPES[dtype], _ptr(_dev(x)), _ptr(_dev(g)), _ptr(_dev(b)), rows, C_, act,
+                                    _ptr(out32), _ptr(out16), None)
+        _lib.check(rc, "s3enc_op_layernorm")
+        torch.cuda.synchronize()
+        assert O.rel_err(out32.cpu().numpy(), ref) < 2e-6
+        if out16 is not None:
+            assert O.rel_err(out16.float().cpu().numpy(), ref) < 5e-3
+
+
+def _attention_ref(qkv, valid, B, T, H, table=None, gate=None):
+    D = H * 64
+    q = qkv[:, :D].reshape(B, T, H, 64).transpose(0, 2, 1, 3)
+    k = qkv[:, D:2 * D].reshape(B, T, H, 64).transpose(0, 2, 1, 3)
+    v = qkv[:, 2 * D:].reshape(B, T, H, 64).transpose(0, 2, 1, 3)
+    s = q @ k.transpose(0, 1, 3, 2)
+    if table is not None:
+        idx = (np.arange(T)[None, :] - np.arange(T)[:, None]) + T - 1  # [i][j] -> (j - i) + T - 1
+        bias = table[:, idx]  # (H,T,T)
+        gt = gate if gate is not None else np.ones((B, H, T))
+        s = s + gt[..., None] * bias[None]
+    for b in range(B):
+        s[b, :, :, valid[b]:] = -np.inf
+    s = s - s.max(-1, keepdims=True)
+    p = np.exp(s)
+    p /= p.sum(-1, keepdims=True)
+    return (p @ v).transpose(0, 2, 1, 3).reshape(B * T, D)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
+@pytest.mark.parametrize("T,rel", [(33, False), (200, False), (149, True), (499, False)])
+def test_attention(dtype, T, rel):
+    torch = _torch()
+    from s3prl_amd import _lib
+
+    lib = _lib.load()
+    rng = np.random.default_rng(T)
+    B, H = 3, 2
+    D = 64 * H
+    qkv = rng.standard_normal((B * T, 3 * D)).astype(np.float32)
+    qkv[:, :D] *= 0.35  # q arrives pre-scaled; keep logits O(few)
+    # one outlier key per batch row exercises the online-softmax rescale
+    qkv[T // 2, D:2 * D] *= 4.0
+    valid = np.array([T, max(1, T // 3), max(1, T - 7)], dtype=np.int32)
+    table = gate = None
+    if rel:
+        table = rng.standard_normal((H, 2 * T - 1)).astype(np.float32)
+        gate = (1 + rng.random((B, H, T))).astype(np.float32)
+    qr = _round(qkv, dtype).astype(np.float64)
+    ref = _attention_ref(qr, valid, B, T, H, None if table is None else table.astype(np.float64),
+                         None if gate is None else gate.astype(np.float64))
+    dq = _dev(qkv, dtype)
+    out = torch.zeros((B * T, D), device="cuda", dtype=dq.dtype)
+    rc = lib.s3enc_op_attention(_lib.DTYPES[dtype], _ptr(dq), _ptr(out), _ptr(torch.from_numpy(valid).cuda()), B, T, H,
+                                _ptr(_dev(table)) if rel else None, _ptr(_dev(gate)) if rel else None, None)
+    _lib.check(rc, "s3enc_op_attention")
+    torch.cuda.synchronize()
+    got = out.float().cpu().numpy()
+    assert np.isfinite(got).all()
+    err = O.rel_err(got, ref)
+    assert err < {"fp32": 2e-5, "bf16": 1.5e-2, "fp16": 2e-3}[dtype], f"attention {dtype} T={T}: rel-err {err:.3e}"
