@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""Headline benchmark: encoder-frames/sec (20 ms stride), HuBERT-base, 32 x 10 s @16 kHz per GPU.
+
+    python bench.py --gpus 1 --steps K --warmup W [--dtype fp32|bf16|fp16]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one full pass of the hot path over one batch: raw waveforms already resident in HBM ->
+all NL+1 hidden_states (fp32, (B,T,D) each) in HBM; with N > 1 every rank encodes its own 32 utterances
+(weak scaling) and the batch's hidden states are re-assembled on every rank by per-layer RCCL all-gathers
+(inside the timed region).  Rank 0 prints ONE JSON line.
+
+Extra objects in the line:
+  roofline     — the dominant kernel (the MFMA GEMM that serves conv1-6 and every linear layer): algorithmic
+                 FLOPs / summed HIP-event time of its launches inside the timed region vs the dense MFMA peak
+                 of the compute dtype (MI355X_MICROARCH.md: 157.3 TF fp32-in, 2500 TF bf16/f16).
+  cpu_baseline — the numpy oracle (a port of the reference forward, oracle/encoder_oracle.py) timed on this
+                 box's host cores on a bounded sample of the same workload (N=1, rank 0 only); its outputs also
+                 give the `parity` figure (max per-layer relative error of the HIP path on that sample).
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0, "fp16": 2500.0}
+
+
+def flops_per_utt(cfg, n):
+    """Algorithmic FLOPs of one n-sample utterance (SURVEY §8d formula)."""
+    L = cfg.conv_lengths(n)
+    C, D, F, NL = cfg.conv_dim, cfg.encoder_embed_dim, cfg.encoder_ffn_embed_dim, cfg.encoder_layers
+    cin, f = 1, 0.0
+    for (_, k, _), l in zip(cfg.conv_layers, L):
+        f += 2.0 * cin * C * k * l
+        cin = C
+    T = L[-1]
+    Tp = T + (T % 2) if cfg.family != "wavlm" else T
+    f += 2.0 * T * C * D + 2.0 * T * D * (D // cfg.conv_pos_groups) * cfg.conv_pos
+    f += NL * (2.0 * Tp * (4 * D * D + 2 * D * F) + 4.0 * Tp * Tp * D)
+    return f
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--dtype", default=os.environ.get("S3ENC_BENCH_DTYPE", "fp32"), choices=["fp32", "bf16", "fp16"])
+    ap.add_argument("--model", default="hubert_base")
+    ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
+    ap.add_argument("--secs", type=float, default=10.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=4, help="utterances of the workload timed on the CPU oracle")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    from s3prl_amd.encoder import HipEncoder
+    from s3prl_amd.synth import named_config, synth_weights
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    if args.gpus != world:
+        if rank == 0:
+            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    cfg = named_config(args.model)
+    weights = synth_weights(cfg, 0)  # random-init weights of the named architecture (no checkpoints offline)
+    enc = HipEncoder(cfg, weights, dtype=args.dtype, device=dev.index)
+    n = int(args.secs * 16000)
+    B = args.batch
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    wavs = [torch.randn(n, device=dev, generator=gen) for _ in range(B)]
+    T = enc.num_frames(n)
+    NL, D = cfg.encoder_layers, cfg.encoder_embed_dim
+    out = torch.empty((NL + 1, B, T, D), dtype=torch.float32, device=dev)
+    gathered = torch.empty((NL + 1, world * B, T, D), dtype=torch.float32, device=dev) if world > 1 else None
+
+    def step():
+        enc.forward(wavs, out=out)
+        if world > 1:
+            # one all-gather per layer so that hidden_states[l] is a contiguous (B_global, T, D) block
+            works = [dist.all_gather_into_tensor(gathered[l], out[l], async_op=True) for l in range(NL + 1)]
+            for w in works:
+                w.wait()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    enc.profile_reset()
+    enc.profile_enable(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    enc.profile_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    prof = enc.profile_read()
+
+    if rank == 0:
+        frames = world * B * T * args.steps
+        ms_per_step = elapsed / args.steps * 1e3
+        value = frames / elapsed
+        gem = [p for p in prof if p["name"].startswith("gemm:")]
+        g_ms = sum(p["ms"] for p in gem)
+        g_fl = sum(p["flops"] for p in gem)
+        g_n = sum(p["launches"] for p in gem)
+        achieved = g_fl / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
+        peak = PEAK_TFLOPS[args.dtype]
+        total_ms = sum(p["ms"] for p in prof)
+        line = {
+            "metric": "encoder-frames/sec (20 ms stride) HuBERT-base 32x10 s @16 kHz",
+            "value": round(value, 1),
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": {"fp32": "f32", "bf16": "bf16", "fp16": "f16"}[args.dtype],
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.model} random-init, {B}x{args.secs:g} s @16 kHz per GPU, all {NL + 1} hidden_states "
+                            f"(fp32) written; per-layer RCCL all-gather across {world} GPU(s)",
+                "utterances_per_gpu": B, "samples": n, "frames_per_utt": T, "parallelism": f"dp{world}",
+            },
+            "path_tflops": round(world * B * flops_per_utt(cfg, n) / (ms_per_step * 1e-3) / 1e12, 2),
+            "roofline": {
+                "kernel": "gemm_kernel (conv1-6 implicit GEMM + proj/qkv/out_proj/fc1/fc2)",
+                "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(achieved / peak, 4), "traffic": None,
+                "launches_per_step": g_n // max(args.steps, 1), "avg_launch_ms": round(g_ms / max(g_n, 1), 4),
+                "share_of_kernel_time": round(g_ms / total_ms, 3) if total_ms else None,
+            },
+            "kernels_ms_per_step": {p["name"]: round(p["ms"] / args.steps, 4) for p in sorted(prof, key=lambda p: -p["ms"])},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import encoder_oracle as O  # checker + CPU baseline only; never on the product path
+
+            ns = max(1, min(args.cpu_sample, B))
+            sample = [w.cpu().numpy() for w in wavs[:ns]]
+            t1 = time.perf_counter()
+            ref = O.forward(cfg, weights, sample, dtype=np.float32)
+            cpu_s = time.perf_counter() - t1
+            hs = enc.forward(wavs[:ns])
+            torch.cuda.synchronize()
+            errs = [O.rel_err(hs[l].cpu().numpy(), ref[l]) for l in range(NL + 1)]
+            line["cpu_baseline"] = {
+                "value": round(ns * T / cpu_s, 1), "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
+                "sample": f"{ns}x{args.secs:g} s of the same workload through oracle/encoder_oracle.py (numpy fp32, "
+                          f"BLAS threads = host cores), {cpu_s:.1f} s wall",
+            }
+            line["parity"] = {"max_layer_rel_err_vs_oracle": float(f"{max(errs):.3e}"), "sample": f"{ns} utterances",
+                              "tolerance": 1e-3}
+        print(json.dumps(line))
+    enc.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

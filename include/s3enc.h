@@ -121,8 +121,8 @@ typedef struct s3enc_profile_entry {
 } s3enc_profile_entry;
 int s3enc_profile_read(s3enc_handle h, s3enc_profile_entry* entries, int32_t max_entries, int32_t* n_entries);
 
-/* Copy an intermediate of the LAST forward to the host as fp32 (test hook): "conv0".."conv6", "feat_ln",
- * "proj", "posconv", "qkv0", "attn0".  Synchronises. */
+/* Copy an intermediate of the LAST forward to the host as fp32 (test hook): the last three conv layers
+ * ("conv4".."conv6" for the 7-layer stack), "feat_ln", "proj", "posconv", "qkv0", "attn0".  Synchronises. */
 int s3enc_debug_tap(s3enc_handle h, const char* name, float* host_out, int64_t max_elems, int64_t* n_elems);
 
 /* ---- single-kernel entry points (parity tests of each HIP kernel against the oracle) -------------------

@@ -636,7 +636,6 @@ int forward_impl(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
         p.out = actA;
         Prof pr(e, st, "conv0", 2.0 * B * L[0] * C * p.k0, 4.0 * B * n_max + (double)B * L[0] * C * es);
         HIP_TRY(launch_conv0(dt, p, st));
-        e->taps["conv0"] = {actA, (long)B * L[0] * C, dt};
     }
     // conv1..: implicit GEMM on channel-last activations
     void* cur = actA;
@@ -678,7 +677,7 @@ int forward_impl(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
         }
         char tn[16];
         snprintf(tn, sizeof(tn), "conv%d", i);
-        e->taps[tn] = {dst, (long)B * L[i] * C, last ? F32 : dt};
+        if (i >= c.n_conv - 3) e->taps[tn] = {dst, (long)B * L[i] * C, last ? F32 : dt};  // earlier ones get overwritten
         cur = dst;
     }
     // LayerNorm(C) -> post_extract_proj (+ zero padded frames)

@@ -129,7 +129,8 @@ def test_layernorm(dtype, C_):
             ref = O.gelu(ref)
         out32 = torch.empty((rows, C_), device="cuda")
         out16 = torch.empty((rows, C_), device="cuda", dtype=torch.bfloat16) if dtype == "bf16" else None
-        rc = lib.s3enc_op_layernorm(_lib.DTYPES[dtype], _ptr(_dev(x)), _ptr(_dev(g)), _ptr(_dev(b)), rows, C_, act,
+        dx, dg, db = _dev(x), _dev(g), _dev(b)  # keep the device tensors alive across the call
+        rc = lib.s3enc_op_layernorm(_lib.DTYPES[dtype], _ptr(dx), _ptr(dg), _ptr(db), rows, C_, act,
                                     _ptr(out32), _ptr(out16), None)
         _lib.check(rc, "s3enc_op_layernorm")
         torch.cuda.synchronize()
@@ -181,8 +182,11 @@ def test_attention(dtype, T, rel):
                          None if gate is None else gate.astype(np.float64))
     dq = _dev(qkv, dtype)
     out = torch.zeros((B * T, D), device="cuda", dtype=dq.dtype)
-    rc = lib.s3enc_op_attention(_lib.DTYPES[dtype], _ptr(dq), _ptr(out), _ptr(torch.from_numpy(valid).cuda()), B, T, H,
-                                _ptr(_dev(table)) if rel else None, _ptr(_dev(gate)) if rel else None, None)
+    dvalid = torch.from_numpy(valid).cuda()
+    dtable = _dev(table) if rel else None  # keep the device tensors alive across the call
+    dgate = _dev(gate) if rel else None
+    rc = lib.s3enc_op_attention(_lib.DTYPES[dtype], _ptr(dq), _ptr(out), _ptr(dvalid), B, T, H, _ptr(dtable), _ptr(dgate),
+                                None)
     _lib.check(rc, "s3enc_op_attention")
     torch.cuda.synchronize()
     got = out.float().cpu().numpy()

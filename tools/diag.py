@@ -22,7 +22,7 @@ def stage_report(name, dtype="fp32"):
     taps = {}
     ref = O.forward(cfg, weights, wavs, dtype=np.float64, taps=taps)
     print(f"== {name} [{dtype}] finite={np.isfinite(hs).all()}")
-    for i in range(len(cfg.conv_layers)):
+    for i in range(len(cfg.conv_layers) - 3, len(cfg.conv_layers)):
         got = enc.debug_tap(f"conv{i}").reshape(taps[f"conv{i}"].shape)
         print(f"   conv{i}: {O.rel_err(got, taps[f'conv{i}']):.3e}")
     got = enc.debug_tap("proj").reshape(taps["proj"].shape)
