@@ -98,13 +98,18 @@ def main():
     out = torch.empty((NL + 1, B, T, D), dtype=torch.float32, device=dev)
     gathered = torch.empty((NL + 1, world * B, T, D), dtype=torch.float32, device=dev) if world > 1 else None
 
+    events = None
+    if world > 1:
+        from s3prl_amd.parallel import gather_layers
+
+        events = enc.layer_events()
+
     def step():
         enc.forward(wavs, out=out)
         if world > 1:
-            # one all-gather per layer so that hidden_states[l] is a contiguous (B_global, T, D) block
-            works = [dist.all_gather_into_tensor(gathered[l], out[l], async_op=True) for l in range(NL + 1)]
-            for w in works:
-                w.wait()
+            # one all-gather per layer (hidden_states[l] stays a contiguous (B_global, T, D) block), issued on a
+            # side stream as soon as layer l is final so it overlaps the remaining layers' compute
+            gather_layers(out, overlap_events=events, out=gathered)
 
     for _ in range(args.warmup):
         step()

@@ -103,6 +103,11 @@ int s3enc_valid_frames(s3enc_handle h, int64_t length, int64_t n_max, int32_t* v
 int s3enc_forward(s3enc_handle h, const float* const* wavs, const int64_t* lengths, int32_t B, int64_t n_max,
                   float* out, int64_t layer_stride, void* stream);
 
+/* Optional: `n` = encoder_layers+1 hipEvent_t handles (as void*); the following forwards record events[l] on the
+ * launch stream as soon as hidden_states[l] is final, so a communication stream can start the all-gather of layer l
+ * while later layers are still computing.  n = 0 clears.  The events stay owned by the caller. */
+int s3enc_set_layer_events(s3enc_handle h, void* const* events, int32_t n);
+
 /* Same, for a zero-padded (B, row_stride) device buffer (what pad_sequence builds, hubert/expert.py:66). */
 int s3enc_forward_padded(s3enc_handle h, const float* pcm, int64_t row_stride, const int64_t* lengths, int32_t B,
                          int64_t n_max, float* out, int64_t layer_stride, void* stream);

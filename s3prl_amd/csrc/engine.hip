@@ -145,6 +145,8 @@ struct s3enc_encoder {
     hipEvent_t slot_ev[RING] = {};
     int slot_next = 0;
 
+    std::vector<hipEvent_t> layer_events;  // caller-owned, recorded when hidden_states[l] is final
+
     // profiling
     bool prof = false;
     std::vector<std::string> kinds;
@@ -735,6 +737,7 @@ int forward_impl(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
         HIP_TRY(launch_layernorm(dt, (const float*)xpc, (const float*)e->eln_g.p, (const float*)e->eln_b.p, M, D, 0, hs0,
                                  dt == F32 ? nullptr : xT, st));
     }
+    if (!e->layer_events.empty()) HIP_TRY(hipEventRecord(e->layer_events[0], st));
     // WavLM relative-position table for this T
     const float* d_table = nullptr;
     if (c.rel_pos) {
@@ -878,6 +881,7 @@ int forward_impl(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
             HIP_TRY(launch_layernorm(dt, (const float*)tmp2, (const float*)e->eln_g.p, (const float*)e->eln_b.p, M, D, 0, x_out,
                                      nullptr, st));
         }
+        if (!e->layer_events.empty()) HIP_TRY(hipEventRecord(e->layer_events[l + 1], st));
     }
     return 0;
 }
@@ -902,6 +906,17 @@ int s3enc_forward_padded(s3enc_handle h, const float* pcm, int64_t row_stride, c
         ptrs[b] = pcm + (long)b * row_stride;
     }
     return forward_impl(h, ptrs.data(), lengths, B, n_max, out, layer_stride, (hipStream_t)stream);
+}
+
+int s3enc_set_layer_events(s3enc_handle h, void* const* events, int32_t n) {
+    if (!h) return fail("null handle");
+    if (n == 0) {
+        h->layer_events.clear();
+        return 0;
+    }
+    if (!events || n != h->cfg.encoder_layers + 1) return fail("s3enc_set_layer_events: need encoder_layers+1 events");
+    h->layer_events.assign((hipEvent_t const*)events, (hipEvent_t const*)events + n);
+    return 0;
 }
 
 int s3enc_profile_enable(s3enc_handle h, int32_t on) {

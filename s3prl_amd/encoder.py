@@ -109,6 +109,23 @@ class HipEncoder:
         _lib.check(rc, "s3enc_forward")
         return out
 
+    def layer_events(self):
+        """NL+1 CUDA events, recorded by every following forward when hidden_states[l] is final (created once)."""
+        import torch
+
+        if getattr(self, "_events", None) is None:
+            dev = torch.device("cuda", self.device)
+            evs = []
+            with torch.cuda.device(dev):
+                for _ in range(self.num_layers + 1):
+                    ev = torch.cuda.Event(enable_timing=False)
+                    ev.record(torch.cuda.current_stream(dev))  # torch creates the hipEvent_t lazily: force it
+                    evs.append(ev)
+            raw = (C.c_void_p * len(evs))(*[int(ev.cuda_event) for ev in evs])
+            _lib.check(self._lib.s3enc_set_layer_events(self._h, raw, len(evs)), "s3enc_set_layer_events")
+            self._events = evs
+        return self._events
+
     # ---- measurement / test hooks ----
     def profile_enable(self, on: bool = True):
         _lib.check(self._lib.s3enc_profile_enable(self._h, int(on)))

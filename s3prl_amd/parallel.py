@@ -1,0 +1,108 @@
+"""Data-parallel encoding of one batch over the GPUs of a node: one process per GPU, utterances sharded in
+contiguous blocks, hidden states re-assembled with per-layer all-gathers over RCCL (``torch.distributed`` backend
+"nccl" on ROCm) — SURVEY §8e.
+
+Reference quirks that couple an utterance to its batch (GroupNorm over the padded length, the ``n_max // T`` frame
+mask, T itself) all depend only on the GLOBAL ``n_max``: every rank pads its shard to it, and the
+gathered result equals the single-GPU full-batch forward.
+
+The sharding / gathering logic is device-agnostic (``encode_fn`` does the work), so it is covered on CPU with the
+gloo backend; on the GPU ``encode_fn`` is ``HipUpstreamExpert.encode`` and the all-gather of layer l is issued on a
+side stream as soon as the library signals that hidden_states[l] is final, overlapping the remaining layers.
+"""
+
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import torch
+
+
+def shard_bounds(B: int, world: int, rank: int) -> Tuple[int, int, int]:
+    """Contiguous block of utterances for ``rank``: (begin, end, per_rank) with per_rank = ceil(B / world).
+    Trailing ranks may own fewer (or zero) real utterances; gathers run on per_rank rows and the pad rows are dropped."""
+    per = -(-B // world)
+    beg = min(B, rank * per)
+    end = min(B, beg + per)
+    return beg, end, per
+
+
+def encode_data_parallel(encode_fn: Callable[[List[torch.Tensor], int], torch.Tensor], wavs: Sequence[torch.Tensor],
+                         group=None, overlap_events: Optional[list] = None) -> List[torch.Tensor]:
+    """Every rank passes the SAME full list ``wavs`` (only its own shard has to be resident on its device);
+    returns ``hidden_states``: NL+1 tensors of shape (B, T, D), identical on every rank, in input order.
+
+    ``encode_fn(shard_wavs, n_max) -> (NL+1, Bs, T, D)`` runs the encoder on the shard padded to ``n_max``.
+    """
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    B = len(wavs)
+    n_max = max(int(w.numel()) for w in wavs)
+    beg, end, per = shard_bounds(B, world, rank)
+    mine = list(wavs[beg:end])
+    while len(mine) < per:  # pad the shard with a copy of a real utterance; its rows are dropped after the gather
+        mine.append(wavs[min(beg, B - 1)] if not mine else mine[-1])
+    hs = encode_fn(mine, n_max)  # (NL+1, per, T, D)
+    if world == 1:
+        return [hs[l][:B] for l in range(hs.shape[0])]
+    gathered = gather_layers(hs, group=group, overlap_events=overlap_events)
+    # rank r's block holds utterances [r*per, r*per + per) → already in input order; drop the pad rows at the end
+    return [gathered[l][:B] for l in range(gathered.shape[0])]
+
+
+_COMM_STREAMS = {}
+
+
+def gather_layers(hs: torch.Tensor, group=None, overlap_events: Optional[list] = None,
+                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """All-gather a rank-local (NL+1, Bs, T, D) slab into (NL+1, world*Bs, T, D): ONE all-gather per layer, so every
+    ``hidden_states[l]`` comes out as a contiguous (B, T, D) block in rank order (a single flat gather would be
+    rank-major across layers, SURVEY §7 hard part 5).  With ``overlap_events`` (CUDA events recorded by the encoder
+    when layer l is final) the gather of layer l is issued on a side stream and overlaps the remaining compute."""
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    NLp1, Bs, T, D = hs.shape
+    if out is None:
+        out = torch.empty((NLp1, world * Bs, T, D), dtype=hs.dtype, device=hs.device)
+    works = []
+    if overlap_events is not None and hs.is_cuda:
+        key = hs.device.index
+        if key not in _COMM_STREAMS:
+            _COMM_STREAMS[key] = torch.cuda.Stream(device=hs.device)
+        comm = _COMM_STREAMS[key]
+        for l in range(NLp1):
+            with torch.cuda.stream(comm):
+                comm.wait_event(overlap_events[l])
+                works.append(dist.all_gather_into_tensor(out[l], hs[l], group=group, async_op=True))
+    else:
+        for l in range(NLp1):
+            works.append(dist.all_gather_into_tensor(out[l], hs[l], group=group, async_op=True))
+    for w in works:
+        w.wait()
+    return out
+
+
+class DataParallelUpstream(torch.nn.Module):
+    """Wraps a ``HipUpstreamExpert``: same ``forward(wavs) -> dict`` contract, batch sharded over the process group."""
+
+    def __init__(self, expert, group=None, overlap: bool = True):
+        super().__init__()
+        self.expert = expert
+        self.group = group
+        self.overlap = overlap
+
+    def get_downsample_rates(self, key: str = None) -> int:
+        return self.expert.get_downsample_rates(key)
+
+    def forward(self, wavs):
+        events = None
+        if self.overlap and wavs[0].is_cuda:
+            events = self.expert._encoder_for(wavs[0].device).layer_events()
+        hidden = tuple(encode_data_parallel(self.expert.encode, wavs, self.group, events))
+        result = {"hidden_states": hidden, "last_hidden_state": hidden[-1]}
+        for i, h in enumerate(hidden):
+            result[f"hidden_state_{i}"] = h
+        return result

@@ -125,3 +125,54 @@ def test_errors_are_reported_not_thrown(golden_loader):
     with pytest.raises(ValueError):
         enc.forward([torch.zeros(100).cuda()])  # shorter than the receptive field
     enc.close()
+
+
+def test_hub_expert_contract(tmp_path, golden_loader):
+    """The drop-in boundary end to end: converted-checkpoint file -> hub entry -> UpstreamExpert -> result dict
+    (SURVEY §8b), compared with the reference golden."""
+    import torch
+    import s3prl_amd.hub as hub
+    from s3prl_amd.ckpt import save_checkpoint
+
+    meta, cfg, weights, wavs, golden, _ = golden_loader("tiny_wavlm_pad")
+    path = str(tmp_path / "wavlm.pt")
+    save_checkpoint(path, cfg, weights)
+    expert = hub.wavlm_local(ckpt=path, refresh=False).cuda().eval()
+    with torch.no_grad():
+        res = expert([torch.from_numpy(w).cuda() for w in wavs])
+    hs = res["hidden_states"]
+    assert isinstance(hs, tuple) and len(hs) == cfg.encoder_layers + 1
+    assert res["last_hidden_state"] is hs[-1] and res["hidden_state_0"] is hs[0]
+    assert all(h.is_cuda and h.dtype == torch.float32 and h.shape == hs[0].shape for h in hs)
+    assert expert.get_downsample_rates("hidden_states") == 320
+    for h, g in zip(hs, golden):
+        assert O.rel_err(h.cpu().numpy(), g) < FP32_TOL
+    # length contract S3PRLUpstream / Featurizer rely on (nn/upstream.py:166-179, interfaces.py:250-261)
+    assert abs(hs[0].shape[1] - round(max(meta["lengths"]) / 320)) < 5
+
+
+def test_layer_events_and_gather_single_rank(golden_loader):
+    """The overlap plumbing of the data-parallel path (events recorded by the library, all-gather issued on a side
+    stream) on a 1-rank RCCL group: the gathered slab must equal the local one."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from s3prl_amd.parallel import gather_layers
+
+    _, cfg, weights, wavs, _, _ = golden_loader("tiny_hubert_pad")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29613")
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        enc = _encoder(cfg, weights)
+        events = enc.layer_events()
+        dev = [torch.from_numpy(w).cuda() for w in wavs]
+        plain = enc.forward(dev).clone()
+        hs = enc.forward(dev)
+        gathered = gather_layers(hs, overlap_events=events)
+        torch.cuda.synchronize()
+        assert torch.equal(gathered, plain)
+        enc.close()
+    finally:
+        dist.destroy_process_group()
