@@ -130,6 +130,10 @@ int s3enc_profile_read(s3enc_handle h, s3enc_profile_entry* entries, int32_t max
  * ("conv4".."conv6" for the 7-layer stack), "feat_ln", "proj", "posconv", "qkv0", "attn0".  Synchronises. */
 int s3enc_debug_tap(s3enc_handle h, const char* name, float* host_out, int64_t max_elems, int64_t* n_elems);
 
+/* Process-wide tuning knobs (kernel-variant selection for A/B measurements; results are unchanged):
+ *   "gemm_variant": 0 = 128-B K stages, 1 = 64-B stages (3 workgroups/CU), 2/3 = same with fragment prefetch. */
+int s3enc_set_tuning(const char* key, int32_t value);
+
 /* ---- single-kernel entry points (parity tests of each HIP kernel against the oracle) -------------------
  * All pointers are device pointers; dtype is S3ENC_F32/BF16/F16 for the 16-bit-capable operands
  * (16-bit data are raw uint16). */

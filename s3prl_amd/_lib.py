@@ -57,6 +57,7 @@ _PROTOS = {
     "s3enc_profile_reset": (C.c_int, [_VP]),
     "s3enc_profile_read": (C.c_int, [_VP, C.POINTER(S3ProfileEntry), _I32, C.POINTER(_I32)]),
     "s3enc_debug_tap": (C.c_int, [_VP, C.c_char_p, C.POINTER(C.c_float), _I64, C.POINTER(_I64)]),
+    "s3enc_set_tuning": (C.c_int, [C.c_char_p, _I32]),
     "s3enc_op_gemm": (C.c_int, [_I32, _VP, _I64, _I64, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _VP, _VP, _VP, _VP,
                                 _I64, _I64, _VP]),
     "s3enc_op_layernorm": (C.c_int, [_I32, _VP, _VP, _VP, _I32, _I32, _I32, _VP, _VP, _VP]),

@@ -981,6 +981,16 @@ int s3enc_debug_tap(s3enc_handle h, const char* name, float* host_out, int64_t m
     return 0;
 }
 
+int s3enc_set_tuning(const char* key, int32_t value) {
+    if (!key) return fail("s3enc_set_tuning: null key");
+    if (!strcmp(key, "gemm_variant")) {
+        if (value < 0 || value > 7) return fail("gemm_variant must be 0..7");
+        g_gemm_variant = value;
+        return 0;
+    }
+    return fail(std::string("s3enc_set_tuning: unknown key '") + key + "'");
+}
+
 // ---- single-kernel entry points -------------------------------------------------------------------------------
 int s3enc_op_gemm(int32_t dtype, const void* A, int64_t lda, int64_t a_batch_stride, const void* W, const float* bias, int32_t M,
                   int32_t N, int32_t K, int32_t batches, int32_t act, const float* residual, const int32_t* row_limit,

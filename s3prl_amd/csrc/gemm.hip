@@ -11,10 +11,15 @@
 // store: fp32 (residual stream / LayerNorm input) and/or the 16-bit operand of the next GEMM.
 //
 // Tiling: 128x128 output tile per 256-thread workgroup (4 wave64 as 2x2, 64x64 per wave = 2x2
-// MFMA 32x32 tiles, 64 accumulator VGPRs).  A K-tile is 128 BYTES of every row for both operands
-// (32 fp32 / 64 bf16|f16), staged global -> VGPR -> LDS with a register double buffer, LDS double
-// buffered, one barrier per K-tile.  LDS rows are 128 B with the 16-B slot XOR-swizzled by
-// ((row>>1)&7) so that every ds_read_b128 fragment read is bank-conflict free (MI355X_MICROARCH §LDS).
+// MFMA 32x32 tiles, 64 accumulator VGPRs).  A K-stage is ROWB = 64 (default) or 128 BYTES of every row of
+// both operands, double buffered in LDS, one barrier per stage; 64-byte stages need 32 KiB of LDS so four
+// workgroups share a CU (VGPR-limited), which measured +5..10 % (fp32) / +20..40 % (bf16) over 128-byte stages.
+// Staging is either global -> VGPR -> ds_write (register double buffer; handles a ragged K tail) or, when K is a
+// multiple of the stage, LDS-DMA (global_load_lds_dwordx4: no staging VGPRs, no ds_write pass).
+// LDS rows are XOR-swizzled at 16-byte granularity (slot ^= f(row)) so every ds_read_b128 fragment read is
+// bank-conflict free (MI355X_MICROARCH §LDS); with LDS-DMA the LDS image is lane-linear, so the same
+// permutation is applied to the per-lane SOURCE address instead (cdna_hip_programming.md rule 21).
+// Workgroups are mapped XCD-aware: every XCD (private L2) gets a contiguous range of (batch, m-tile, n-tile).
 // MFMA: v_mfma_f32_32x32x2_f32 (exact fp32) or v_mfma_f32_32x32x16_{bf16,f16}, fp32 accumulate.
 // The k index inside a K-tile is permuted identically for A and W (each half-wave owns one
 // contiguous 64-byte half of the row) so fragments are read as 16-byte vectors.
@@ -24,9 +29,8 @@ namespace s3 {
 
 namespace {
 
-constexpr int BM = 128, BN = 128, ROWB = 128;  // tile rows / cols, bytes of K per row per stage
-constexpr int STAGE_BYTES = (BM + BN) * ROWB;  // 32 KiB
-constexpr int GEMM_LDS = 2 * STAGE_BYTES;      // 64 KiB
+constexpr int BM = 128, BN = 128;  // tile rows / cols
+// ROWB = bytes of K per row per LDS stage (128: 64 KiB of LDS, 2 workgroups/CU; 64: 32 KiB, VGPR-limited 3/CU)
 
 template <typename T> struct Mma;
 template <> struct Mma<float> {
@@ -48,10 +52,17 @@ template <> struct Mma<f16_tag> {
     }
 };
 
-template <typename T>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
+template <typename T, int ROWB, bool GLDS>
+__global__ __launch_bounds__(256, ROWB == 128 ? 2 : 3) void gemm_kernel(GemmParams p) {
     typedef typename Cvt<T>::store_t store_t;
     constexpr int EB = sizeof(store_t);
+    constexpr int STAGE_BYTES = (BM + BN) * ROWB;
+    constexpr int SLOTS = ROWB / 16;          // 16-byte slots per row per stage (8 or 4)
+    constexpr int SMASK = SLOTS - 1;
+    constexpr int SSH = ROWB == 128 ? 1 : 2;  // swizzle: slot ^= (row >> SSH) & SMASK
+    constexpr int RPT = 256 / SLOTS;          // rows covered by one pass of the 256 loader threads (32 or 64)
+    constexpr int NLD = BM / RPT;             // 16-byte loads per thread per operand per stage (4 or 2)
+    constexpr int NQ = SLOTS / 2;             // fragment steps per stage (4 or 2)
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -61,54 +72,53 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
     const int half = lane >> 5;
     const int l31 = lane & 31;
 
+    // XCD-aware tile order: workgroup w runs on XCD w%8 (each XCD has a private 4 MiB L2), so give every XCD a
+    // CONTIGUOUS range of the (batch, m-tile, n-tile) sequence with n fastest: the n-tiles that share an A row panel
+    // and the m-tiles that share W run back to back on the same L2 (bijective for any grid size).
     const int n_tiles = (p.N + BN - 1) / BN;
-    const int tm = blockIdx.x / n_tiles, tn = blockIdx.x % n_tiles;
-    const int b = blockIdx.y;
+    const int m_tiles = (p.M + BM - 1) / BM;
+    int tile;
+    {
+        const int nwg = gridDim.x, wg = blockIdx.x;
+        if (p.variant & 4) {
+            tile = wg;
+        } else {
+            const int q8 = nwg >> 3, r8 = nwg & 7, xcd = wg & 7, loc = wg >> 3;
+            tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
+        }
+    }
+    const int tn = tile % n_tiles;
+    const int tmb = tile / n_tiles;
+    const int tm = tmb % m_tiles, b = tmb / m_tiles;
     const int m0 = tm * BM, n0 = tn * BN;
 
     const long lda_b = p.lda * EB;
     const long kbytes = (long)p.K * EB;  // bytes of one full row of K
     const char* Ab = (const char*)p.A + (long)b * p.a_bs * EB;
     const char* Wb = (const char*)p.W;
+    const int nk = (int)((kbytes + ROWB - 1) / ROWB);
 
-    // ---- loader: thread owns 16-B slot `ls` of rows lr, lr+32, lr+64, lr+96 of both operand tiles ----
-    const int ls = tid & 7;
-    const int lr = tid >> 3;
-    const char* a_ptr[4];
-    const char* w_ptr[4];
+    // ---- loader: thread owns one 16-B slot of rows lr, lr+RPT, ... of both operand tiles.  Consecutive lanes fill
+    //      consecutive 16-B slots of LDS (lane-linear: what LDS-DMA requires); the slot each lane FETCHES is the
+    //      swizzle-inverse, so the LDS image ends up swizzled either way. ----
+    const int ps = tid & SMASK;   // physical slot
+    const int lr = tid / SLOTS;   // row within a pass
+    const int ls = ps ^ ((lr >> SSH) & SMASK);  // logical slot (RPT is a multiple of 16: same for every pass)
+    const char* a_ptr[NLD];
+    const char* w_ptr[NLD];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int ra = m0 + lr + 32 * i;
+    for (int i = 0; i < NLD; ++i) {
+        int ra = m0 + lr + RPT * i;
         ra = ra < p.M ? ra : p.M - 1;
-        int rw = n0 + lr + 32 * i;
+        int rw = n0 + lr + RPT * i;
         rw = rw < p.N ? rw : p.N - 1;
         a_ptr[i] = Ab + (long)ra * lda_b + ls * 16;
         w_ptr[i] = Wb + (long)rw * kbytes + ls * 16;
     }
-    const int st_off = lr * ROWB + ((ls ^ ((lr >> 1) & 7)) << 4);  // + i*32*ROWB
-
-    uint4 ga[4], gw[4];
-    auto load_tile = [&](int kt) {
-        const long kb = (long)kt * ROWB;
-        const bool ok = kb + ls * 16 < kbytes;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            ga[i] = ok ? *(const uint4*)(a_ptr[i] + kb) : make_uint4(0, 0, 0, 0);
-            gw[i] = ok ? *(const uint4*)(w_ptr[i] + kb) : make_uint4(0, 0, 0, 0);
-        }
-    };
-    auto store_tile = [&](int stage) {
-        char* sa = smem + stage * STAGE_BYTES;
-        char* sw = sa + BM * ROWB;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *(uint4*)(sa + st_off + i * 32 * ROWB) = ga[i];
-            *(uint4*)(sw + st_off + i * 32 * ROWB) = gw[i];
-        }
-    };
+    const int st_off = lr * ROWB + (ps << 4);  // + i*RPT*ROWB ; == tid*16 + i*4096
 
     // ---- fragment addresses ----
-    const int swz = (l31 >> 1) & 7;
+    const int swz = (l31 >> SSH) & SMASK;
     const int a_row0 = (wr * 64 + l31) * ROWB;
     const int w_row0 = BM * ROWB + (wc * 64 + l31) * ROWB;
 
@@ -120,17 +130,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = (int)((kbytes + ROWB - 1) / ROWB);
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) load_tile(kt + 1);
-        const char* st = smem + cur * STAGE_BYTES;
+    auto compute = [&](int stage) {
+        const char* st = smem + stage * STAGE_BYTES;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int so = ((half * 4 + q) ^ swz) << 4;
+        for (int q = 0; q < NQ; ++q) {
+            const int so = ((half * NQ + q) ^ swz) << 4;
             uint4 fa[2], fb[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) fa[i] = *(const uint4*)(st + a_row0 + i * 32 * ROWB + so);
@@ -141,8 +145,58 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
         }
-        if (kt + 1 < nk) store_tile(cur ^ 1);
+    };
+
+    if constexpr (GLDS) {
+        // LDS-DMA staging: each wave instruction lands 64 x 16 B = 1 KiB contiguously at a wave-uniform LDS base
+        auto issue = [&](int kt, int stage) {
+            const long kb = (long)kt * ROWB;
+            char* sa = smem + stage * STAGE_BYTES + wave * 1024;  // == st_off - lane*16
+            char* sw = sa + BM * ROWB;
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_ptr[i] + kb),
+                                                 (__attribute__((address_space(3))) void*)(sa + i * 4096), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_ptr[i] + kb),
+                                                 (__attribute__((address_space(3))) void*)(sw + i * 4096), 16, 0, 0);
+            }
+        };
+        issue(0, 0);
         __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+            compute(kt & 1);
+            __syncthreads();  // drains this wave's DMA (vmcnt) and orders everyone's reads before the next overwrite
+        }
+    } else {
+        uint4 ga[NLD], gw[NLD];
+        auto load_tile = [&](int kt) {
+            const long kb = (long)kt * ROWB;
+            const bool ok = kb + ls * 16 < kbytes;
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                ga[i] = ok ? *(const uint4*)(a_ptr[i] + kb) : make_uint4(0, 0, 0, 0);
+                gw[i] = ok ? *(const uint4*)(w_ptr[i] + kb) : make_uint4(0, 0, 0, 0);
+            }
+        };
+        auto store_tile = [&](int stage) {
+            char* sa = smem + stage * STAGE_BYTES;
+            char* sw = sa + BM * ROWB;
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                *(uint4*)(sa + st_off + i * RPT * ROWB) = ga[i];
+                *(uint4*)(sw + st_off + i * RPT * ROWB) = gw[i];
+            }
+        };
+        load_tile(0);
+        store_tile(0);
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) load_tile(kt + 1);
+            compute(kt & 1);
+            if (kt + 1 < nk) store_tile((kt + 1) & 1);
+            __syncthreads();
+        }
     }
 
     // ---- epilogue: acc[i][j][r] is (row = wr*64+i*32 + (r&3)+8*(r>>2)+4*half, col = wc*64+j*32+l31) ----
@@ -171,38 +225,45 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
     }
 }
 
+template <typename T, int ROWB, bool GLDS>
+hipError_t gemm_go(const GemmParams& p, dim3 grid, hipStream_t stream) {
+    constexpr int lds = 2 * (BM + BN) * ROWB;
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<T, ROWB, GLDS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((gemm_kernel<T, ROWB, GLDS>), grid, dim3(256), lds, stream, p);
+    return hipGetLastError();
+}
+
+// variant bits: 1 = 64-byte K stages (else 128), 2 = LDS-DMA staging, 4 = no XCD-aware tile order (A/B only)
+template <typename T>
+hipError_t gemm_variant(const GemmParams& p, dim3 grid, hipStream_t stream, bool k_aligned64, bool k_aligned128) {
+    const bool small = p.variant & 1;
+    const bool glds = (p.variant & 2) && (small ? k_aligned64 : k_aligned128);  // DMA cannot zero-fill a ragged K tail
+    if (small) return glds ? gemm_go<T, 64, true>(p, grid, stream) : gemm_go<T, 64, false>(p, grid, stream);
+    return glds ? gemm_go<T, 128, true>(p, grid, stream) : gemm_go<T, 128, false>(p, grid, stream);
+}
+
 }  // namespace
 
-hipError_t launch_gemm(int dtype, const GemmParams& p, hipStream_t stream) {
+int g_gemm_variant = 1;
+
+hipError_t launch_gemm(int dtype, const GemmParams& p0, hipStream_t stream) {
+    GemmParams p = p0;
+    if (p.variant < 0) p.variant = g_gemm_variant;
     if (p.M <= 0 || p.N <= 0 || p.batches <= 0) return hipSuccess;
     const int eb = dtype == F32 ? 4 : 2;
     // 16-byte vector loads: row starts and K must be 16-byte granular
     if (((p.lda * eb) & 15) || ((p.a_bs * eb) & 15) || (((long)p.K * eb) & 15) || (((uintptr_t)p.A) & 15) ||
         (((uintptr_t)p.W) & 15))
         return hipErrorInvalidValue;
-    dim3 grid(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN), p.batches);
-    dim3 block(256);
-    hipError_t e;
+    dim3 grid(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.batches);
+    const bool a64 = (((long)p.K * eb) & 63) == 0, a128 = (((long)p.K * eb) & 127) == 0;
     switch (dtype) {
-        case F32:
-            e = hipFuncSetAttribute((const void*)gemm_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
-            if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(gemm_kernel<float>, grid, block, GEMM_LDS, stream, p);
-            break;
-        case BF16:
-            e = hipFuncSetAttribute((const void*)gemm_kernel<bf16_tag>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
-            if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(gemm_kernel<bf16_tag>, grid, block, GEMM_LDS, stream, p);
-            break;
-        case F16:
-            e = hipFuncSetAttribute((const void*)gemm_kernel<f16_tag>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
-            if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(gemm_kernel<f16_tag>, grid, block, GEMM_LDS, stream, p);
-            break;
-        default:
-            return hipErrorInvalidValue;
+        case F32: return gemm_variant<float>(p, grid, stream, a64, a128);
+        case BF16: return gemm_variant<bf16_tag>(p, grid, stream, a64, a128);
+        case F16: return gemm_variant<f16_tag>(p, grid, stream, a64, a128);
     }
-    return hipGetLastError();
+    return hipErrorInvalidValue;
 }
 
 }  // namespace s3

@@ -17,7 +17,9 @@ struct GemmParams {
     float* out32;
     void* out16;
     long ldo, o_bs;
+    int variant = -1;  // tuning knob: -1 = library default (g_gemm_variant)
 };
+extern int g_gemm_variant;
 hipError_t launch_gemm(int dtype, const GemmParams& p, hipStream_t stream);
 
 // ---- frontend.hip ---------------------------------------------------------------------------------------

@@ -44,6 +44,21 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", ["plain", "conv", "edge"])
+def test_gemm_variants(dtype, case, variant):
+    """Every staging variant (128/64-byte K stages x register-staged / LDS-DMA) computes the same GEMM."""
+    from s3prl_amd import _lib
+
+    lib = _lib.load()
+    _lib.check(lib.s3enc_set_tuning(b"gemm_variant", variant))
+    try:
+        test_gemm(dtype, case)
+    finally:
+        _lib.check(lib.s3enc_set_tuning(b"gemm_variant", 1))
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("case", ["plain", "conv", "epilogue", "edge"])
 def test_gemm(dtype, case):

@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""A/B micro-benchmark of the GEMM kernel variants on the shapes of the HuBERT-base forward (within one process,
+interleaved rounds).  usage: gemm_bench.py [dtype ...]"""
+import ctypes as C, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from s3prl_amd import _lib
+
+lib = _lib.load()
+SHAPES = {  # name: (batches, M, N, K, lda, a_bs_rows)
+    "conv1": (32, 15999, 512, 1536, 1024, 31999),
+    "conv2": (32, 7999, 512, 1536, 1024, 15999),
+    "qkv": (1, 15968, 2304, 768, 768, None),
+    "out_proj": (1, 15968, 768, 768, 768, None),
+    "fc1": (1, 15968, 3072, 768, 768, None),
+    "fc2": (1, 15968, 768, 3072, 3072, None),
+}
+
+def run(dtype, variants=(1, 3, 0, 2), rounds=5):
+    td = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[dtype]
+    print(f"== {dtype}")
+    for name, (nb, M, N, K, lda, rows) in SHAPES.items():
+        if rows is None:
+            A = torch.randn(M * lda, device="cuda").to(td); a_bs = M * lda
+        else:
+            A = torch.randn(nb * rows * 512, device="cuda").to(td); a_bs = rows * 512
+        W = (torch.randn(N, K, device="cuda") / K ** 0.5).to(td)
+        bias = torch.randn(N, device="cuda")
+        out32 = torch.empty(nb * M * N, device="cuda") if dtype == "fp32" else None
+        out16 = torch.empty(nb * M * N, device="cuda", dtype=td) if dtype != "fp32" else None
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        res = {v: [] for v in variants}
+        ref = None
+        for r in range(rounds + 1):
+            for v in variants:
+                _lib.check(lib.s3enc_set_tuning(b"gemm_variant", v))
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                _lib.check(lib.s3enc_op_gemm(_lib.DTYPES[dtype], p(A), lda, a_bs, p(W), p(bias), M, N, K, nb, 1, None, None,
+                                             p(out32), p(out16), N, M * N, None))
+                e1.record(); torch.cuda.synchronize()
+                if r: res[v].append(e0.elapsed_time(e1))
+                o = (out32 if out32 is not None else out16).float()
+                chk = float(o[:: 9973].double().sum())
+                if ref is None: ref = chk
+                assert abs(chk - ref) <= 1e-3 * abs(ref) + 1e-3, (name, v, chk, ref)
+        fl = 2.0 * nb * M * N * K
+        print(f"  {name:9s}", "  ".join(f"v{v}: {min(t):7.3f} ms {fl / min(t) / 1e9:7.1f} TF" for v, t in res.items()))
+
+if __name__ == "__main__":
+    for d in (sys.argv[1:] or ["fp32", "bf16"]):
+        run(d)
