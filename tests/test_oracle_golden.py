@@ -54,3 +54,23 @@ def test_shard_padded_to_global_max_reproduces_full_batch(golden_loader):
         assert O.rel_err(shard[l], g[2:]) < REL_TOL
     local = O.forward(cfg, weights, wavs[2:], dtype=np.float32)  # padded to the shard's own max: different
     assert local[0].shape[1] != golden[0].shape[1] or O.rel_err(local[0], golden[0][2:]) > 1e-2
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_torch_oracle_matches_reference_golden(name, golden_loader):
+    """oracle/torch_oracle.py (the ATen-call-site restatement timed as bench.py's cpu_baseline) against the same
+    reference-generated fixtures."""
+    import torch
+
+    from oracle import torch_oracle as TO
+
+    meta, cfg, weights, wavs, golden, norms = golden_loader(name)
+    hs = TO.forward(cfg, TO.prepare(cfg, weights), [torch.from_numpy(w) for w in wavs])
+    assert len(hs) == len(golden)
+    ts, cs = meta["t_stride"], meta["c_stride"]
+    for l, (h, g) in enumerate(zip(hs, golden)):
+        h = h.numpy()
+        assert list(h.shape) == meta["shape"]
+        err = O.rel_err(h[:, ::ts, ::cs], g)
+        assert err < REL_TOL, f"{name} layer {l}: rel-err {err:.3e}"
+        assert abs(np.linalg.norm(h.astype(np.float64)) - norms[l]) / norms[l] < REL_TOL
