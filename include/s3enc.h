@@ -131,7 +131,8 @@ int s3enc_profile_read(s3enc_handle h, s3enc_profile_entry* entries, int32_t max
 int s3enc_debug_tap(s3enc_handle h, const char* name, float* host_out, int64_t max_elems, int64_t* n_elems);
 
 /* Process-wide tuning knobs (kernel-variant selection for A/B measurements; results are unchanged):
- *   "gemm_variant": 0 = 128-B K stages, 1 = 64-B stages (3 workgroups/CU), 2/3 = same with fragment prefetch. */
+ *   "gemm_variant": bit 0 = 64-byte K stages (else 128), bit 1 = LDS-DMA staging, bit 2 = no XCD-aware tile order;
+ *   "gemm16_big":   large-tile kernel of the 16-bit modes: 0 off, 1 = 256x256 tiles, 2 = 128x256, 3 = by tile count. */
 int s3enc_set_tuning(const char* key, int32_t value);
 
 /* ---- single-kernel entry points (parity tests of each HIP kernel against the oracle) -------------------

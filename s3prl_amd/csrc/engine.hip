@@ -988,6 +988,11 @@ int s3enc_set_tuning(const char* key, int32_t value) {
         g_gemm_variant = value;
         return 0;
     }
+    if (!strcmp(key, "gemm16_big")) {
+        if (value < 0 || value > 5) return fail("gemm16_big must be 0..5");
+        g_gemm16_big = value;
+        return 0;
+    }
     return fail(std::string("s3enc_set_tuning: unknown key '") + key + "'");
 }
 

@@ -1,0 +1,308 @@
+// gemm16.hip — large-tile variant of the dense-contraction kernel for the 16-bit operand modes (bf16 / f16).
+//
+//   out[b][m][n] = epilogue( sum_k A[b][m][k] * W[n][k] )        (same contract as gemm.hip)
+//
+// Why a second kernel: at the 16-bit MFMA rate (16x the fp32 rate) the 128x128 / 4-wave tile of gemm.hip is
+// bounded by what feeds the matrix pipe, not by the pipe: 64 FLOP per byte staged from L2 and 1 KiB of LDS reads per
+// MFMA.  Here a 512-thread workgroup owns a (2*WTM) x 256 tile, 8 wave64 as 2(M) x 4(N), each wave a WTM x 64
+// sub-tile (WTM = 128: 8 accumulator tiles of 32x32 = 128 VGPRs; 128 FLOP per staged byte, 0.75 KiB LDS per MFMA).
+//   * staging: LDS-DMA only (global_load_lds_dwordx4, 1 KiB per wave instruction, whole 128-byte lines of a row
+//     per 8 lanes), two stages of 64 K-values, the next stage in flight while the current one is multiplied;
+//     LDS rows are XOR-swizzled through the per-lane SOURCE address (the DMA image is lane-linear) so every
+//     ds_read_b128 fragment read is bank-conflict free — same layout as gemm.hip's 128-byte stages.
+//   * epilogue: accumulators go through a wave-private LDS transpose (32 x 64 fp32 per step) so that bias, GELU,
+//     residual and the padded-frame zeroing run on row-contiguous float4s and every global access is a full
+//     16-byte (fp32) / 8-byte (16-bit) vector: 8 store instructions per 32x64 block instead of 32.
+//   * GELU in the 16-bit modes uses a 1.5e-7-accurate erf (Abramowitz-Stegun 7.1.26: one v_exp + one v_rcp + a
+//     degree-5 Horner) instead of libm's erff: at K = 768 the erff epilogue costs about as many VALU cycles as the
+//     whole K loop costs MFMA cycles.  The error is 3 orders below the operand rounding of these modes; the fp32
+//     mode (gemm.hip) keeps erff.
+// Requirements (checked by the launcher, which otherwise falls back to gemm.hip): K a multiple of 64, N / ldo /
+// o_bs multiples of 4, 16-byte aligned operands and outputs.
+#include "kernels.h"
+
+namespace s3 {
+
+namespace {
+
+constexpr int BN = 256;  // tile columns
+
+template <typename T> struct Mma16;
+template <> struct Mma16<bf16_tag> {
+    static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x16& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+};
+template <> struct Mma16<f16_tag> {
+    static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x16& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+};
+
+// erf-GELU with |erf error| <= 1.5e-7 (Abramowitz & Stegun 7.1.26)
+__device__ __forceinline__ float gelu_fast(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    poly *= t;
+    const float e = __builtin_amdgcn_exp2f(-1.44269504088896340736f * z * z);
+    const float erf_abs = fmaf(-poly, e, 1.0f);
+    const float erf = __builtin_copysignf(erf_abs, x);
+    return 0.5f * x * (1.0f + erf);
+}
+
+// WTM: rows per wave (tile = 2*WTM x 256); ROWB: bytes of K per row per LDS stage (128 or 64); NST: LDS stages (2: the
+// next stage lands while this one is multiplied; 3: two stages in flight, counted vmcnt); WPE: waves per SIMD the
+// register budget is capped for (2 = one workgroup per CU, 4 = two).
+template <typename T, int WTM, int ROWB, int NST, int WPE>
+__global__ __launch_bounds__(512, WPE) void gemm16_big_kernel(GemmParams p) {
+    constexpr int BM = 2 * WTM;
+    constexpr int MI = WTM / 32;  // 32-row accumulator blocks per wave
+    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int SLOTS = ROWB / 16, SMASK = SLOTS - 1;  // 16-byte slots per row per stage
+    constexpr int SSH = ROWB == 128 ? 1 : 2;              // swizzle: slot ^= (row >> SSH) & SMASK
+    constexpr int RPP = 512 / SLOTS;                      // rows filled by one pass of the 8 waves (64 or 128)
+    constexpr int NLA = BM / RPP, NLB = BN / RPP;         // LDS-DMA instructions per wave per stage and operand
+    constexpr int NQ = SLOTS / 2;                         // 16-deep fragment steps per stage
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wr = wave >> 2, wc = wave & 3;
+    const int half = lane >> 5;
+    const int l31 = lane & 31;
+
+    // XCD-aware tile order (see gemm.hip): every XCD gets a contiguous range of (batch, m-tile, n-tile), n fastest
+    const int n_tiles = (p.N + BN - 1) / BN;
+    const int m_tiles = (p.M + BM - 1) / BM;
+    int tile;
+    {
+        const int nwg = gridDim.x, wg = blockIdx.x;
+        const int q8 = nwg >> 3, r8 = nwg & 7, xcd = wg & 7, loc = wg >> 3;
+        tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
+    }
+    const int tn = tile % n_tiles;
+    const int tmb = tile / n_tiles;
+    const int tm = tmb % m_tiles, b = tmb / m_tiles;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const long lda_b = p.lda * 2;
+    const long kbytes = (long)p.K * 2;
+    const char* Ab = (const char*)p.A + (long)b * p.a_bs * 2;
+    const char* Wb = (const char*)p.W;
+    const int nk = (int)(kbytes / ROWB);
+
+    // ---- loader: lane (lr, ps) fills physical 16-byte slot ps of row lr (+64 per pass) and FETCHES the logical slot
+    //      ps ^ swizzle(row): 8 lanes read one whole 128-byte line of a row ----
+    const int ps = tid & SMASK;
+    const int lr = tid / SLOTS;  // 0..RPP-1
+    const int ls = ps ^ ((lr >> SSH) & SMASK);
+    const char* a_ptr[NLA];
+    const char* w_ptr[NLB];
+#pragma unroll
+    for (int i = 0; i < NLA; ++i) {
+        int ra = m0 + lr + RPP * i;
+        ra = ra < p.M ? ra : p.M - 1;
+        a_ptr[i] = Ab + (long)ra * lda_b + ls * 16;
+    }
+#pragma unroll
+    for (int i = 0; i < NLB; ++i) {
+        int rw = n0 + lr + RPP * i;
+        rw = rw < p.N ? rw : p.N - 1;
+        w_ptr[i] = Wb + (long)rw * kbytes + ls * 16;
+    }
+    // LDS-DMA issued from inline asm: hipcc does not count it, so it inserts no vmcnt(0) in front of the fragment
+    // ds_reads of the stage being multiplied (with the builtin it does — the DMA is a pending LDS write it cannot
+    // disambiguate — which serialises load and compute); completion is waited for by hand before the stage barrier.
+    // M0 (the wave-uniform LDS destination) is written in the same statement that uses it and restored.
+    const unsigned lds_base =
+        __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem + wave * 1024);
+    auto glds16 = [&](const char* gsrc, unsigned lds_dst) {
+        unsigned keep;
+        asm volatile(
+            "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(gsrc), "s"(lds_dst)
+            : "memory");
+    };
+    auto issue = [&](int kt, int stage) {
+        const long kb = (long)kt * ROWB;
+        const unsigned sa = lds_base + stage * STAGE_BYTES;  // wave-uniform; lane l lands at + l*16
+        const unsigned sw = sa + A_BYTES;
+#pragma unroll
+        for (int i = 0; i < NLA; ++i) glds16(a_ptr[i] + kb, sa + i * 8192);
+#pragma unroll
+        for (int i = 0; i < NLB; ++i) glds16(w_ptr[i] + kb, sw + i * 8192);
+    };
+    // my DMA (all of it, or all but the newest stage's NLA + NLB instructions) has landed and my fragment reads are
+    // done; then everybody's
+    auto barrier_all = [&]() {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+    auto barrier_keep_one = [&]() {
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"i"(NLA + NLB) : "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+
+    // ---- fragment addresses ----
+    const int swz = (l31 >> SSH) & SMASK;
+    const int a_row0 = (wr * WTM + l31) * ROWB;
+    const int w_row0 = A_BYTES + (wc * 64 + l31) * ROWB;
+
+    f32x16 acc[MI][2];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto compute = [&](int stage) {
+        const char* st = smem + stage * STAGE_BYTES;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int so = ((half * NQ + q) ^ swz) << 4;
+            uint4 fa[MI], fb[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = *(const uint4*)(st + w_row0 + j * 32 * ROWB + so);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) fa[i] = *(const uint4*)(st + a_row0 + i * 32 * ROWB + so);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) Mma16<T>::run(fa[i], fb[j], acc[i][j]);
+        }
+    };
+
+    if constexpr (NST == 2) {
+        issue(0, 0);
+        barrier_all();  // stage 0 is visible to every wave
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);  // lands while stage kt is multiplied
+            compute(kt & 1);
+            barrier_all();
+        }
+    } else {
+        // ring of 3: the DMA of K-step kt+2 is issued into the stage read during kt-1 (every wave is past that
+        // step's barrier), the one of kt+1 has a whole step left to land
+        issue(0, 0);
+        if (nk > 1) {
+            issue(1, 1);
+            barrier_keep_one();
+        } else {
+            barrier_all();
+        }
+        int cur = 0, nxt = 2;
+        for (int kt = 0; kt < nk; ++kt) {
+            const bool more = kt + 2 < nk;
+            if (more) issue(kt + 2, nxt);
+            compute(cur);
+            if (more) barrier_keep_one(); else barrier_all();
+            cur = cur == 2 ? 0 : cur + 1;
+            nxt = nxt == 2 ? 0 : nxt + 1;
+        }
+    }
+
+    // ---- epilogue through a wave-private LDS transpose: 32 x 64 fp32 per step ----
+    typedef typename Cvt<T>::store_t store_t;
+    float* stg = (float*)(smem + wave * 8192);
+    const int limit = p.row_limit ? p.row_limit[b] : p.M;
+    const long ob = (long)b * p.o_bs;
+    const int c4 = (lane & 15) * 4;
+    const int n = n0 + wc * 64 + c4;
+    const bool n_ok = n < p.N;  // N % 4 == 0: a float4 is inside or outside as a whole
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias && n_ok) bias4 = *(const float4*)(p.bias + n);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                stg[((r & 3) + 8 * (r >> 2) + 4 * half) * 64 + j * 32 + l31] = acc[i][j][r];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int row = t * 4 + (lane >> 4);
+            float4 v = *(const float4*)(stg + row * 64 + c4);
+            const int m = m0 + wr * WTM + i * 32 + row;
+            if (m < p.M && n_ok) {
+                v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+                if (p.act) {
+                    v.x = gelu_fast(v.x); v.y = gelu_fast(v.y); v.z = gelu_fast(v.z); v.w = gelu_fast(v.w);
+                }
+                const long o = ob + (long)m * p.ldo + n;
+                if (p.residual) {
+                    const float4 rs = *(const float4*)(p.residual + o);
+                    v.x += rs.x; v.y += rs.y; v.z += rs.z; v.w += rs.w;
+                }
+                if (m >= limit) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p.out32) *(float4*)(p.out32 + o) = v;
+                if (p.out16) {
+                    ushort4 h;
+                    h.x = Cvt<T>::to(v.x); h.y = Cvt<T>::to(v.y); h.z = Cvt<T>::to(v.z); h.w = Cvt<T>::to(v.w);
+                    *(ushort4*)((store_t*)p.out16 + o) = h;
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+
+template <typename T, int WTM, int ROWB, int NST, int WPE>
+hipError_t big_go(const GemmParams& p, hipStream_t stream) {
+    constexpr int BM = 2 * WTM;
+    constexpr int lds = NST * (BM + BN) * ROWB;
+    static_assert(lds >= 8 * 8192, "epilogue staging must fit");
+    static_assert(lds * (WPE / 2) <= 160 * 1024, "workgroups per CU x LDS");
+    auto kern = gemm16_big_kernel<T, WTM, ROWB, NST, WPE>;
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    dim3 grid(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.batches);
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, p);
+    return hipGetLastError();
+}
+
+template <typename T>
+hipError_t big_mode(int mode, const GemmParams& p, hipStream_t stream) {
+    switch (mode) {
+        case 1: return big_go<T, 128, 128, 2, 2>(p, stream);  // 256x256, 128 KiB, one workgroup per CU
+        case 2: return big_go<T, 64, 128, 2, 2>(p, stream);   // 128x256,  96 KiB, one per CU
+        case 4: return big_go<T, 64, 64, 3, 4>(p, stream);    // 128x256,  72 KiB ring of 3, two per CU
+        case 5: return big_go<T, 128, 64, 3, 2>(p, stream);   // 256x256,  96 KiB ring of 3, one per CU
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace
+
+int g_gemm16_big = 3;  // 0 off, 3 = choose by shape, 1/2/4/5 = force one configuration (see big_mode)
+
+bool gemm16_big_eligible(int dtype, const GemmParams& p) {
+    if (dtype == F32 || g_gemm16_big == 0) return false;
+    if ((p.K & 63) || (p.N & 3) || (p.ldo & 3) || (p.o_bs & 3)) return false;
+    if (((p.lda * 2) & 15) || ((p.a_bs * 2) & 15)) return false;
+    const uintptr_t al = (uintptr_t)p.A | (uintptr_t)p.W | (uintptr_t)p.out32 | (uintptr_t)p.residual | (uintptr_t)p.bias;
+    if (al & 15) return false;
+    if (((uintptr_t)p.out16) & 7) return false;
+    return p.M >= 128 && p.N >= 128;
+}
+
+hipError_t launch_gemm16_big(int dtype, const GemmParams& p, hipStream_t stream) {
+    int mode = g_gemm16_big;
+    if (mode == 3) {
+        // measured on MI355X (tools/gemm_bench.py, profiles/r01_gemm16_variants.md): long K loops amortise the serial
+        // prologue/epilogue of a one-workgroup-per-CU 256x256 tile and gain from its 128 FLOP per staged byte; short
+        // ones (K = 768 / 1024 / 1536) are faster with two 128x256 workgroups per CU hiding each other's barriers and
+        // epilogues
+        mode = p.K >= 2048 ? 1 : 4;
+    }
+    return dtype == BF16 ? big_mode<bf16_tag>(mode, p, stream) : big_mode<f16_tag>(mode, p, stream);
+}
+
+}  // namespace s3

@@ -20,6 +20,10 @@ struct GemmParams {
     int variant = -1;  // tuning knob: -1 = library default (g_gemm_variant)
 };
 extern int g_gemm_variant;
+// gemm16.hip: large-tile LDS-DMA kernel for the 16-bit modes (0 off, 1 = 256x256, 2 = 128x256, 3 = by tile count)
+extern int g_gemm16_big;
+bool gemm16_big_eligible(int dtype, const GemmParams& p);
+hipError_t launch_gemm16_big(int dtype, const GemmParams& p, hipStream_t stream);
 hipError_t launch_gemm(int dtype, const GemmParams& p, hipStream_t stream);
 
 // ---- frontend.hip ---------------------------------------------------------------------------------------

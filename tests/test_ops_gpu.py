@@ -59,6 +59,23 @@ def test_gemm_variants(dtype, case, variant):
         _lib.check(lib.s3enc_set_tuning(b"gemm_variant", 1))
 
 
+@pytest.mark.parametrize("mode", [1, 2, 4, 5, 0])
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("case", ["big_plain", "big_conv", "big_epilogue", "big_edge"])
+def test_gemm16_big_tiles(dtype, case, mode):
+    """The large-tile LDS-DMA kernel of the 16-bit modes (gemm16.hip): 256x256 (mode 1) and 128x256 (mode 2) tiles on
+    shapes that span several tiles with ragged M / N edges, overlapping conv rows, batches and the full epilogue;
+    mode 0 runs the same shapes through the 128x128 kernel."""
+    from s3prl_amd import _lib
+
+    lib = _lib.load()
+    _lib.check(lib.s3enc_set_tuning(b"gemm16_big", mode))
+    try:
+        test_gemm(dtype, case)
+    finally:
+        _lib.check(lib.s3enc_set_tuning(b"gemm16_big", 3))
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("case", ["plain", "conv", "epilogue", "edge"])
 def test_gemm(dtype, case):
@@ -68,10 +85,22 @@ def test_gemm(dtype, case):
     lib = _lib.load()
     rng = np.random.default_rng(zlib.crc32(f"{dtype}/{case}".encode()))
     act, use_res, use_lim = 0, False, False
+    Cc, Lin = 64, 301
     if case == "plain":
         batches, M, N, K, lda = 1, 300, 384, 256, 256
+    elif case == "big_plain":
+        batches, M, N, K, lda = 1, 700, 516, 320, 320
+    elif case == "big_conv":
+        Cc, Lin = 128, 1101
+        M = (Lin - 3) // 2 + 1
+        batches, N, K, lda = 3, 256, 3 * Cc, 2 * Cc
+        act = 1
+    elif case == "big_epilogue":
+        batches, M, N, K, lda = 2, 530, 264, 128, 136
+        act, use_res, use_lim = 1, True, True
+    elif case == "big_edge":
+        batches, M, N, K, lda = 2, 129, 132, 64, 64
     elif case == "conv":  # Conv1d(C, C, k=3, s=2) on channel-last rows: lda = 2C < K = 3C
-        Cc, Lin = 64, 301
         M = (Lin - 3) // 2 + 1
         batches, N, K, lda = 3, 64, 3 * Cc, 2 * Cc
         act = 1
@@ -80,7 +109,7 @@ def test_gemm(dtype, case):
         act, use_res, use_lim = 1, True, True
     else:  # ragged everything: M, N not multiples of the tile, K with a partial 128-byte stage
         batches, M, N, K, lda = 2, 77, 72, 200, 200
-    if case == "conv":
+    if case in ("conv", "big_conv"):
         a_bs = Lin * Cc
         A = rng.standard_normal((batches, Lin * Cc)).astype(np.float32)
     else:

@@ -15,12 +15,22 @@ SHAPES = {  # name: (batches, M, N, K, lda, a_bs_rows)
     "out_proj": (1, 15968, 768, 768, 768, None),
     "fc1": (1, 15968, 3072, 768, 768, None),
     "fc2": (1, 15968, 768, 3072, 3072, None),
+    "L_qkv": (1, 15968, 3072, 1024, 1024, None),
+    "L_out": (1, 15968, 1024, 1024, 1024, None),
+    "L_fc1": (1, 15968, 4096, 1024, 1024, None),
+    "L_fc2": (1, 15968, 1024, 4096, 4096, None),
 }
 
-def run(dtype, variants=(1, 3, 0, 2), rounds=5):
+def run(dtype, variants=None, rounds=5, shapes=None, reps=10):
+    big = dtype != "fp32"
+    if variants is None:
+        # 16-bit modes: the large-tile kernel's configurations (gemm16_big; 0 = the 128x128 kernel); fp32: staging variants
+        variants = (0, 1, 2, 4, 5) if big else (1, 3, 0, 2)
     td = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[dtype]
     print(f"== {dtype}")
     for name, (nb, M, N, K, lda, rows) in SHAPES.items():
+        if shapes and name not in shapes:
+            continue
         if rows is None:
             A = torch.randn(M * lda, device="cuda").to(td); a_bs = M * lda
         else:
@@ -34,14 +44,15 @@ def run(dtype, variants=(1, 3, 0, 2), rounds=5):
         ref = None
         for r in range(rounds + 1):
             for v in variants:
-                _lib.check(lib.s3enc_set_tuning(b"gemm_variant", v))
+                _lib.check(lib.s3enc_set_tuning(b"gemm16_big" if big else b"gemm_variant", v))
                 torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                _lib.check(lib.s3enc_op_gemm(_lib.DTYPES[dtype], p(A), lda, a_bs, p(W), p(bias), M, N, K, nb, 1, None, None,
-                                             p(out32), p(out16), N, M * N, None))
+                for _ in range(reps):  # back-to-back launches: one launch alone is dominated by clock ramp / launch gaps
+                    _lib.check(lib.s3enc_op_gemm(_lib.DTYPES[dtype], p(A), lda, a_bs, p(W), p(bias), M, N, K, nb, 1, None,
+                                                 None, p(out32), p(out16), N, M * N, None))
                 e1.record(); torch.cuda.synchronize()
-                if r: res[v].append(e0.elapsed_time(e1))
+                if r: res[v].append(e0.elapsed_time(e1) / reps)
                 o = (out32 if out32 is not None else out16).float()
                 chk = float(o[:: 9973].double().sum())
                 if ref is None: ref = chk
@@ -50,5 +61,14 @@ def run(dtype, variants=(1, 3, 0, 2), rounds=5):
         print(f"  {name:9s}", "  ".join(f"v{v}: {min(t):7.3f} ms {fl / min(t) / 1e9:7.1f} TF" for v, t in res.items()))
 
 if __name__ == "__main__":
-    for d in (sys.argv[1:] or ["fp32", "bf16"]):
-        run(d)
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("dtypes", nargs="*", default=["fp32", "bf16"])
+    ap.add_argument("--shapes", default="")
+    ap.add_argument("--variants", default="")
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--reps", type=int, default=10)
+    a = ap.parse_args()
+    for d in a.dtypes:
+        run(d, tuple(int(v) for v in a.variants.split(",")) if a.variants else None, a.rounds,
+            set(a.shapes.split(",")) if a.shapes else None, a.reps)
