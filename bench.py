@@ -14,9 +14,12 @@ Extra objects in the line:
   roofline     — the dominant kernel (the MFMA GEMM that serves conv1-6 and every linear layer): algorithmic
                  FLOPs / summed HIP-event time of its launches inside the timed region vs the dense MFMA peak
                  of the compute dtype (MI355X_MICROARCH.md: 157.3 TF fp32-in, 2500 TF bf16/f16).
-  cpu_baseline — the numpy oracle (a port of the reference forward, oracle/encoder_oracle.py) timed on this
-                 box's host cores on a bounded sample of the same workload (N=1, rank 0 only); its outputs also
-                 give the `parity` figure (max per-layer relative error of the HIP path on that sample).
+  cpu_baseline — oracle/torch_oracle.py (the reference forward restated on the reference's own ATen call sites:
+                 F.conv1d / F.group_norm / F.multi_head_attention_forward ..., PyTorch CPU fp32, all host threads —
+                 /root/reference itself does not exist on the GPU box) timed on this box's host cores on a bounded
+                 sample of the same workload (N=1, rank 0 only).
+  parity       — max per-layer relative error of the HIP path on a sample, against the independent numpy oracle
+                 (oracle/encoder_oracle.py) and against the torch restatement.
 """
 
 from __future__ import annotations
@@ -32,6 +35,20 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0, "fp16": 2500.0}
+MODEL_NAMES = {"hubert_base": "HuBERT-base", "hubert_large": "HuBERT-large", "wav2vec2_base": "wav2vec2-base",
+               "wav2vec2_large": "wav2vec2-large", "wavlm_base_plus": "WavLM-base+", "wavlm_large": "WavLM-large"}
+
+
+def pmc_traffic(path, model, dtype, batch, secs):
+    """HBM-side bytes per launch of the dominant kernel, from the committed PMC passes of this same workload
+    (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md §HBM); None when no matching record is committed."""
+    try:
+        for rec in json.load(open(path)):
+            if (rec["model"], rec["dtype"], rec["batch"], rec["secs"]) == (model, dtype, batch, secs):
+                return rec
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
 
 
 def flops_per_utt(cfg, n):
@@ -59,7 +76,10 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
     ap.add_argument("--secs", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=4, help="utterances of the workload timed on the CPU oracle")
+    ap.add_argument("--cpu-sample", type=int, default=8, help="utterances of the workload timed on the CPU oracle")
+    ap.add_argument("--parity-sample", type=int, default=2, help="utterances checked against the numpy oracle")
+    ap.add_argument("--traffic", default=os.path.join(ROOT, "profiles", "traffic.json"),
+                    help="per-kernel HBM-side bytes from the committed rocprofv3 PMC passes (tools/pmc.sh)")
     args = ap.parse_args()
 
     import numpy as np
@@ -141,11 +161,12 @@ def main():
         g_ms = sum(p["ms"] for p in gem)
         g_fl = sum(p["flops"] for p in gem)
         g_n = sum(p["launches"] for p in gem)
+        g_by = sum(p["bytes"] for p in gem)
         achieved = g_fl / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
         peak = PEAK_TFLOPS[args.dtype]
         total_ms = sum(p["ms"] for p in prof)
         line = {
-            "metric": "encoder-frames/sec (20 ms stride) HuBERT-base 32x10 s @16 kHz",
+            "metric": f"encoder-frames/sec (20 ms stride) {MODEL_NAMES.get(args.model, args.model)} {B}x{args.secs:g} s @16 kHz",
             "value": round(value, 1),
             "unit": "frames/s",
             "n_gpus": world,
@@ -166,29 +187,56 @@ def main():
             "roofline": {
                 "kernel": "gemm_kernel (conv1-6 implicit GEMM + proj/qkv/out_proj/fc1/fc2)",
                 "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(achieved / peak, 4), "traffic": None,
+                "frac": round(achieved / peak, 4), "traffic": None, "algorithmic_bytes": round(g_by / max(g_n, 1)),
                 "launches_per_step": g_n // max(args.steps, 1), "avg_launch_ms": round(g_ms / max(g_n, 1), 4),
                 "share_of_kernel_time": round(g_ms / total_ms, 3) if total_ms else None,
             },
             "kernels_ms_per_step": {p["name"]: round(p["ms"] / args.steps, 4) for p in sorted(prof, key=lambda p: -p["ms"])},
         }
+        tr = pmc_traffic(args.traffic, args.model, args.dtype, B, args.secs)
+        if tr is not None:
+            line["roofline"]["traffic"] = tr["gemm_bytes_per_launch"]
+            line["roofline"]["traffic_source"] = tr["source"]
         if world == 1 and not args.no_cpu_baseline:
-            from oracle import encoder_oracle as O  # checker + CPU baseline only; never on the product path
+            # checkers + CPU baseline only; never on the product path
+            from oracle import encoder_oracle as O
+            from oracle import torch_oracle as TO
 
             ns = max(1, min(args.cpu_sample, B))
-            sample = [w.cpu().numpy() for w in wavs[:ns]]
+            Wt = TO.prepare(cfg, weights)
+            sample = [w.cpu() for w in wavs[:ns]]
+            # the reference's recipe is set_num_threads(os.cpu_count()); on a many-core host that oversubscribes oneDNN,
+            # so give the CPU path its best thread count: sweep on one utterance, keep the fastest
+            ncpu = os.cpu_count() or 1
+            sweep = {}
+            for th in sorted({min(ncpu, t) for t in (16, 32, 64, 128, ncpu)}):
+                torch.set_num_threads(th)
+                TO.forward(cfg, Wt, sample[:1])  # warm-up (thread pool, oneDNN primitive cache)
+                t1 = time.perf_counter()
+                TO.forward(cfg, Wt, sample[:1])
+                sweep[th] = time.perf_counter() - t1
+            best = min(sweep, key=sweep.get)
+            torch.set_num_threads(best)
             t1 = time.perf_counter()
-            ref = O.forward(cfg, weights, sample, dtype=np.float32)
+            ref_t = TO.forward(cfg, Wt, sample)
             cpu_s = time.perf_counter() - t1
             hs = enc.forward(wavs[:ns])
             torch.cuda.synchronize()
-            errs = [O.rel_err(hs[l].cpu().numpy(), ref[l]) for l in range(NL + 1)]
+            err_t = max(O.rel_err(hs[l].cpu().numpy(), ref_t[l].numpy()) for l in range(NL + 1))
+            npar = max(1, min(args.parity_sample, ns))
+            ref_n = O.forward(cfg, weights, [w.numpy() for w in sample[:npar]], dtype=np.float32)
+            hs_n = enc.forward(wavs[:npar])
+            torch.cuda.synchronize()
+            err_n = max(O.rel_err(hs_n[l].cpu().numpy(), ref_n[l]) for l in range(NL + 1))
             line["cpu_baseline"] = {
-                "value": round(ns * T / cpu_s, 1), "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
-                "sample": f"{ns}x{args.secs:g} s of the same workload through oracle/encoder_oracle.py (numpy fp32, "
-                          f"BLAS threads = host cores), {cpu_s:.1f} s wall",
+                "value": round(ns * T / cpu_s, 1), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+                "sample": f"{ns}x{args.secs:g} s of the same workload through oracle/torch_oracle.py (the reference's ATen "
+                          f"call sites, PyTorch {torch.__version__} CPU fp32, {torch.get_num_threads()} threads on "
+                          f"{os.cpu_count()} host cores — the fastest of a 1-utterance sweep "
+                          f"{ {k: round(v, 2) for k, v in sweep.items()} } s), {cpu_s:.1f} s wall",
             }
-            line["parity"] = {"max_layer_rel_err_vs_oracle": float(f"{max(errs):.3e}"), "sample": f"{ns} utterances",
+            line["parity"] = {"max_layer_rel_err_vs_numpy_oracle": float(f"{err_n:.3e}"), "numpy_sample": f"{npar} utterances",
+                              "max_layer_rel_err_vs_torch_oracle": float(f"{err_t:.3e}"), "torch_sample": f"{ns} utterances",
                               "tolerance": 1e-3}
         print(json.dumps(line))
     enc.close()
