@@ -76,7 +76,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
     ap.add_argument("--secs", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=8, help="utterances of the workload timed on the CPU oracle")
+    ap.add_argument("--cpu-sample", type=int, default=32, help="utterances of the workload timed on the CPU oracle")
     ap.add_argument("--parity-sample", type=int, default=2, help="utterances checked against the numpy oracle")
     ap.add_argument("--traffic", default=os.path.join(ROOT, "profiles", "traffic.json"),
                     help="per-kernel HBM-side bytes from the committed rocprofv3 PMC passes (tools/pmc.sh)")
@@ -205,15 +205,16 @@ def main():
             ns = max(1, min(args.cpu_sample, B))
             Wt = TO.prepare(cfg, weights)
             sample = [w.cpu() for w in wavs[:ns]]
-            # the reference's recipe is set_num_threads(os.cpu_count()); on a many-core host that oversubscribes oneDNN,
-            # so give the CPU path its best thread count: sweep on one utterance, keep the fastest
+            # the reference's recipe is set_num_threads(os.cpu_count()); on a many-core host that oversubscribes oneDNN
+            # (256 threads: 32 s per utterance on the GPU box), so give the CPU path its best thread count: sweep on
+            # a 4-utterance batch, keep the fastest
             ncpu = os.cpu_count() or 1
             sweep = {}
-            for th in sorted({min(ncpu, t) for t in (16, 32, 64, 128, ncpu)}):
+            for th in sorted({min(ncpu, t) for t in (8, 16, 32, 64, 128)}):
                 torch.set_num_threads(th)
                 TO.forward(cfg, Wt, sample[:1])  # warm-up (thread pool, oneDNN primitive cache)
                 t1 = time.perf_counter()
-                TO.forward(cfg, Wt, sample[:1])
+                TO.forward(cfg, Wt, sample[:4])
                 sweep[th] = time.perf_counter() - t1
             best = min(sweep, key=sweep.get)
             torch.set_num_threads(best)
@@ -232,7 +233,7 @@ def main():
                 "value": round(ns * T / cpu_s, 1), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
                 "sample": f"{ns}x{args.secs:g} s of the same workload through oracle/torch_oracle.py (the reference's ATen "
                           f"call sites, PyTorch {torch.__version__} CPU fp32, {torch.get_num_threads()} threads on "
-                          f"{os.cpu_count()} host cores — the fastest of a 1-utterance sweep "
+                          f"{os.cpu_count()} host cores — the fastest of a 4-utterance sweep "
                           f"{ {k: round(v, 2) for k, v in sweep.items()} } s), {cpu_s:.1f} s wall",
             }
             line["parity"] = {"max_layer_rel_err_vs_numpy_oracle": float(f"{err_n:.3e}"), "numpy_sample": f"{npar} utterances",

@@ -157,6 +157,12 @@ int s3enc_op_layernorm(int32_t dtype, const float* x, const float* gamma, const 
 int s3enc_op_attention(int32_t dtype, const void* qkv, void* out, const int32_t* valid, int32_t B, int32_t T,
                        int32_t H, const float* bias_table, const float* gate, void* stream);
 
+/* Convolutional position embedding + residual: out = x + GELU(SamePad(Conv1d(D, D, K, padding=K/2, groups=G)(x)) + bias)
+ * (make_conv_pos / SamePad, wav2vec2_model.py:2937-2953,1797-1808).  x, out: device fp32 (B, T, D); w_host: HOST fp32
+ * (D, D/G, K), the nn.Conv1d weight with weight_norm already folded; packed and uploaded inside.  Synchronises. */
+int s3enc_op_posconv(int32_t dtype, const float* x, const float* w_host, const float* bias, int32_t B, int32_t T, int32_t D,
+                     int32_t G, int32_t K, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -62,6 +62,7 @@ _PROTOS = {
                                 _I64, _I64, _VP]),
     "s3enc_op_layernorm": (C.c_int, [_I32, _VP, _VP, _VP, _I32, _I32, _I32, _VP, _VP, _VP]),
     "s3enc_op_attention": (C.c_int, [_I32, _VP, _VP, _VP, _I32, _I32, _I32, _VP, _VP, _VP]),
+    "s3enc_op_posconv": (C.c_int, [_I32, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _VP, _VP]),
 }
 
 _lib = None

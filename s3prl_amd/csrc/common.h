@@ -10,6 +10,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 enum DType : int { F32 = 0, BF16 = 1, F16 = 2 };
 
@@ -52,6 +53,22 @@ template <> struct Cvt<f16_tag> {
 
 // erf-GELU in fp32: nn.GELU() / F.gelu(x.float()) on the reference path.
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// erf-GELU with |erf error| <= 1.5e-7 (Abramowitz & Stegun 7.1.26: one v_exp, one v_rcp, a degree-5 Horner) for the
+// 16-bit operand modes, where libm erff would cost more VALU cycles than a K = 768 contraction costs MFMA cycles.
+__device__ __forceinline__ float gelu_fast(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    poly *= t;
+    const float e = __builtin_amdgcn_exp2f(-1.44269504088896340736f * z * z);
+    const float erf_abs = fmaf(-poly, e, 1.0f);
+    const float erf = __builtin_copysignf(erf_abs, x);
+    return 0.5f * x * (1.0f + erf);
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -108,6 +108,24 @@ hipError_t upload_cvt(DevBuf& d, const std::vector<float>& v, int dtype) {
     return hipMemcpy(d.p, h.data(), h.size() * 2, hipMemcpyHostToDevice);
 }
 
+// Positional-conv weight (folded, [D][Dg][K] like nn.Conv1d.weight) -> the layout of the kernel of `dtype`:
+//   fp32   [G][K][Dg/16][Dg(co)][16]         (posconv_kernel: tap-major 16-deep input-channel chunks)
+//   16-bit [G][Dg(co)][k = tap*Dg + ci]       (posconv16_kernel: the W operand of the implicit GEMM)
+void pack_posconv(const std::vector<float>& w, int D, int G, int K, int dtype, std::vector<float>& out) {
+    const int Dg = D / G;
+    out.assign((size_t)G * K * Dg * Dg, 0.f);
+    for (int gi = 0; gi < G; ++gi)
+        for (int n = 0; n < Dg; ++n)
+            for (int ci = 0; ci < Dg; ++ci)
+                for (int k = 0; k < K; ++k) {
+                    const float x = w[((long)(gi * Dg + n) * Dg + ci) * K + k];
+                    if (dtype == F32)
+                        out[((((long)gi * K + k) * (Dg / 16) + ci / 16) * Dg + n) * 16 + ci % 16] = x;
+                    else
+                        out[(((long)gi * Dg + n) * K + k) * Dg + ci] = x;
+                }
+}
+
 struct LayerW {
     DevBuf wqkv, bqkv, wo, bo, ln1g, ln1b, w1, b1, w2, b2, ln2g, ln2b;
     DevBuf grep_w, grep_b, grep_a;
@@ -363,7 +381,7 @@ int s3enc_create(const s3enc_config* cfg, const s3enc_tensor* tensors, int32_t n
     GET("post_extract_proj.bias", D, t);
     UP(upload_f32(e->proj_b, t));
 
-    // ---- positional conv: fold weight_norm(dim=2), pack [G][K][Dg/16][Dg][16] ----
+    // ---- positional conv: fold weight_norm(dim=2), then pack for the kernel of the compute dtype ----
     {
         const int K = c.conv_pos, G = c.conv_pos_groups, Dg = D / G;
         std::vector<float> g, v;
@@ -373,16 +391,10 @@ int s3enc_create(const s3enc_config* cfg, const s3enc_tensor* tensors, int32_t n
         for (long i = 0; i < (long)D * Dg; ++i)
             for (int k = 0; k < K; ++k) nrm[k] += (double)v[i * K + k] * v[i * K + k];
         for (int k = 0; k < K; ++k) nrm[k] = (double)g[k] / std::sqrt(nrm[k]);
-        t2.assign((size_t)G * K * Dg * Dg, 0.f);
-        for (int gi = 0; gi < G; ++gi)
-            for (int n = 0; n < Dg; ++n)
-                for (int ci = 0; ci < Dg; ++ci)
-                    for (int k = 0; k < K; ++k) {
-                        const float w = (float)(v[((long)(gi * Dg + n) * Dg + ci) * K + k] * nrm[k]);
-                        const int cc = ci / 16, e16 = ci % 16;
-                        t2[((((long)gi * K + k) * (Dg / 16) + cc) * Dg + n) * 16 + e16] = w;
-                    }
-        UP(upload_f32(e->pos_w, t2));
+        for (long i = 0; i < (long)D * Dg; ++i)
+            for (int k = 0; k < K; ++k) v[i * K + k] = (float)(v[i * K + k] * nrm[k]);
+        pack_posconv(v, D, G, K, e->dtype, t2);
+        UP(upload_cvt(e->pos_w, t2, e->dtype));
         GET("encoder.pos_conv.0.bias", D, t);
         UP(upload_f32(e->pos_b, t));
     }
@@ -720,7 +732,7 @@ int forward_impl(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
     {
         PosConvParams p{};
         p.x = (const float*)x32;
-        p.w = (const float*)e->pos_w.p;
+        p.w = e->pos_w.p;
         p.bias = (const float*)e->pos_b.p;
         p.out = prel ? hs0 : (float*)xpc;
         p.B = B;
@@ -729,7 +741,7 @@ int forward_impl(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
         p.G = c.conv_pos_groups;
         p.K = c.conv_pos;
         Prof pr(e, st, "posconv", 2.0 * M * D * (D / p.G) * p.K, (double)M * D * 8 + (double)D * (D / p.G) * p.K * 4);
-        HIP_TRY(launch_posconv(p, st));
+        HIP_TRY(dt == F32 ? launch_posconv(p, st) : launch_posconv16(dt, p, st));
         e->taps["posconv"] = {p.out, M * D, F32};
     }
     if (!prel) {
@@ -1039,6 +1051,30 @@ int s3enc_op_attention(int32_t dtype, const void* qkv, void* out, const int32_t*
     a.bias_table = bias_table;
     a.gate = gate;
     HIP_TRY(launch_attention(dtype, a, (hipStream_t)stream));
+    return 0;
+}
+
+int s3enc_op_posconv(int32_t dtype, const float* x, const float* w_host, const float* bias, int32_t B, int32_t T, int32_t D,
+                     int32_t G, int32_t K, float* out, void* stream) {
+    if (!x || !w_host || !bias || !out) return fail("s3enc_op_posconv: null argument");
+    if (G <= 0 || D % G) return fail("s3enc_op_posconv: D must be a multiple of groups");
+    const int Dg = D / G;
+    std::vector<float> w(w_host, w_host + (size_t)D * Dg * K), packed;
+    pack_posconv(w, D, G, K, dtype, packed);
+    DevBuf dw;
+    HIP_TRY(upload_cvt(dw, packed, dtype));
+    PosConvParams p{};
+    p.x = x;
+    p.w = dw.p;
+    p.bias = bias;
+    p.out = out;
+    p.B = B;
+    p.T = T;
+    p.D = D;
+    p.G = G;
+    p.K = K;
+    HIP_TRY(dtype == F32 ? launch_posconv(p, (hipStream_t)stream) : launch_posconv16(dtype, p, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));  // the packed weights are freed on return
     return 0;
 }
 

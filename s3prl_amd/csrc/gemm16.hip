@@ -39,21 +39,6 @@ template <> struct Mma16<f16_tag> {
     }
 };
 
-// erf-GELU with |erf error| <= 1.5e-7 (Abramowitz & Stegun 7.1.26)
-__device__ __forceinline__ float gelu_fast(float x) {
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-    float poly = fmaf(1.061405429f, t, -1.453152027f);
-    poly = fmaf(poly, t, 1.421413741f);
-    poly = fmaf(poly, t, -0.284496736f);
-    poly = fmaf(poly, t, 0.254829592f);
-    poly *= t;
-    const float e = __builtin_amdgcn_exp2f(-1.44269504088896340736f * z * z);
-    const float erf_abs = fmaf(-poly, e, 1.0f);
-    const float erf = __builtin_copysignf(erf_abs, x);
-    return 0.5f * x * (1.0f + erf);
-}
-
 // WTM: rows per wave (tile = 2*WTM x 256); ROWB: bytes of K per row per LDS stage (128 or 64); NST: LDS stages (2: the
 // next stage lands while this one is multiplied; 3: two stages in flight, counted vmcnt); WPE: waves per SIMD the
 // register budget is capped for (2 = one workgroup per CU, 4 = two).

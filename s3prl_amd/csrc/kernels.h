@@ -78,11 +78,13 @@ hipError_t launch_wavlm_gate(const float* x, const float* grep_w /*[8][64]*/, co
 // ---- posconv.hip --------------------------------------------------------------------------------------------
 struct PosConvParams {
     const float* x;     // (B, T, D) fp32, padded frames already zero
-    const float* w;     // packed [G][K][Dg/16][Dg(n)][16]
+    const void* w;      // fp32 mode: packed [G][K][Dg/16][Dg(n)][16]; 16-bit modes: see launch_posconv16
     const float* bias;  // [D]
     float* out;         // (B, T, D) fp32 = x + gelu(conv(x) + bias)
     int B, T, D, G, K;
 };
 hipError_t launch_posconv(const PosConvParams& p, hipStream_t s);
+// 16-bit operand modes: p.w = 16-bit pack [G][Dg][K*Dg] with k = tap*Dg + ci; x / out / bias fp32
+hipError_t launch_posconv16(int dtype, const PosConvParams& p, hipStream_t s);
 
 }  // namespace s3

@@ -43,8 +43,8 @@ __global__ __launch_bounds__(256) void posconv_kernel(PosConvParams p) {
         if (ts >= 0 && ts < p.T) v = *(const float4*)(xg + (long)ts * p.D + 4 * c4);
         *(float4*)(xs + rr * RS + 4 * c4) = v;
     }
-    const float4* wg = (const float4*)(p.w + (long)g * K * WSZ);
-    float4 wreg[NWV];
+    const f32x4* wg = (const f32x4*)((const float*)p.w + (long)g * K * WSZ);
+    f32x4 wreg[NWV];  // native vectors: an array of HIP float4 structs held across the loop is left in scratch memory
     auto wload = [&](int j) {
 #pragma unroll
         for (int i = 0; i < NWV; ++i) {
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void posconv_kernel(PosConvParams p) {
 #pragma unroll
         for (int i = 0; i < NWV; ++i) {
             const int e = tid + 256 * i;
-            if (e < WSZ / 4) *(float4*)(wl + buf * WSZ + 4 * e) = wreg[i];
+            if (e < WSZ / 4) *(f32x4*)(wl + buf * WSZ + 4 * e) = wreg[i];
         }
     };
     wload(0);
@@ -115,7 +115,169 @@ hipError_t pc_launch(const PosConvParams& p, hipStream_t s) {
     return hipGetLastError();
 }
 
+
+// ---- 16-bit operand modes ------------------------------------------------------------------------------------------
+// Same contraction on v_mfma_f32_16x16x32_{bf16,f16}.  Per group the Toeplitz GEMM is an IMPLICIT GEMM with
+// overlapping rows, exactly like the strided convs of gemm.hip:  out[t][co] = sum_k A[t][k] * W[co][k] with the k axis
+// flattened as k = j*Dg + ci, W packed [G][Dg][K*Dg] and A[t][k] = window[(t + j)][ci] = the 16-bit window read as one
+// flat array at element t*Dg + k — so a 32-deep MFMA step may straddle taps and Dg = 48 needs no padding.
+// One workgroup = (batch, group, 256 output frames); wave w owns frames [64w, 64w+64) x all Dg channels
+// (4 x Dg/16 accumulator tiles: every W fragment read from LDS feeds 4 MFMAs).  The fp32 input window is converted
+// once and kept in LDS chunk-major ([Dg/8][rows] 16-byte units: the 16 frames of an A fragment are 16 consecutive
+// slots -> conflict-free for any Dg); W streams through a double-buffered, XOR-swizzled LDS tile of 128 k per step
+// (global -> VGPR prefetch -> ds_write, one barrier per 128 k).  Bias, GELU and the fp32 residual are fused.
+constexpr int P16_TM = 256;   // output frames per workgroup
+constexpr int P16_KC = 128;   // k per W stage (16 x 16-byte chunks per row)
+
+template <typename T> struct Mma16x16;
+template <> struct Mma16x16<bf16_tag> {
+    static __device__ __forceinline__ f32x4 run(const uint4& a, const uint4& b, const f32x4& c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+};
+template <> struct Mma16x16<f16_tag> {
+    static __device__ __forceinline__ f32x4 run(const uint4& a, const uint4& b, const f32x4& c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+};
+
+template <typename T, int DG>
+__global__ __launch_bounds__(256) void posconv16_kernel(PosConvParams p) {
+    constexpr int NT = DG / 16;  // 16-wide output-channel tiles
+    constexpr int CH = DG / 8;   // 16-byte chunks per frame
+    constexpr int NLW = DG * 16 / 256;  // 16-byte W pieces per thread per stage
+    constexpr int WBUF = DG * 256;      // bytes per W stage
+    extern __shared__ __attribute__((aligned(16))) char lds16[];
+    const int K = p.K;
+    const int ROWS = (P16_TM + K - 1 + 15) & ~15;  // window rows, padded so chunk planes start on the same bank
+    char* win = lds16;
+    char* wl = lds16 + (size_t)CH * ROWS * 16;
+
+    const int b = blockIdx.z, g = blockIdx.y;
+    const int t0 = blockIdx.x * P16_TM;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, kgrp = lane >> 4;
+    const int pad = K / 2;
+    const long Ktot = (long)K * DG;
+
+    // ---- W stage loader: piece e = (row n, chunk c); LDS slot of chunk c in row n is c ^ (n & 15).
+    //      (macros, not lambdas: a by-reference capture of the register array ends up in scratch memory) ----
+    const char* wg = (const char*)p.w + (long)g * DG * Ktot * 2;
+    u32x4 wreg[NLW];  // native vectors: an array of HIP uint4 structs held across the loop is left in scratch memory
+#define P16_WLOAD(kc_)                                                                                   \
+    _Pragma("unroll") for (int i_ = 0; i_ < NLW; ++i_) {                                               \
+        const int e_ = tid + 256 * i_, n_ = e_ >> 4, c_ = e_ & 15;                                     \
+        wreg[i_] = *(const u32x4*)(wg + ((long)n_ * Ktot + (long)(kc_) * P16_KC + c_ * 8) * 2);        \
+    }
+#define P16_WSTORE(buf_)                                                                                 \
+    _Pragma("unroll") for (int i_ = 0; i_ < NLW; ++i_) {                                               \
+        const int e_ = tid + 256 * i_, n_ = e_ >> 4, c_ = e_ & 15;                                     \
+        *(u32x4*)(wl + (buf_) * WBUF + (n_ * 16 + (c_ ^ (n_ & 15))) * 16) = wreg[i_];                  \
+    }
+    P16_WLOAD(0)
+
+    // ---- input window: fp32 -> 16-bit, chunk-major ----
+    const float* xg = p.x + (long)b * p.T * p.D + g * DG;
+    const int rows = P16_TM + K - 1;
+    for (int idx = tid; idx < ROWS * CH; idx += 256) {
+        const int f = idx % ROWS, cc = idx / ROWS;
+        const int ts = t0 + f - pad;
+        uint4 h = make_uint4(0, 0, 0, 0);
+        if (f < rows && ts >= 0 && ts < p.T) {
+            const float4 v0 = *(const float4*)(xg + (long)ts * p.D + cc * 8);
+            const float4 v1 = *(const float4*)(xg + (long)ts * p.D + cc * 8 + 4);
+            h.x = (unsigned)Cvt<T>::to(v0.x) | ((unsigned)Cvt<T>::to(v0.y) << 16);
+            h.y = (unsigned)Cvt<T>::to(v0.z) | ((unsigned)Cvt<T>::to(v0.w) << 16);
+            h.z = (unsigned)Cvt<T>::to(v1.x) | ((unsigned)Cvt<T>::to(v1.y) << 16);
+            h.w = (unsigned)Cvt<T>::to(v1.z) | ((unsigned)Cvt<T>::to(v1.w) << 16);
+        }
+        *(uint4*)(win + ((size_t)cc * ROWS + f) * 16) = h;
+    }
+    P16_WSTORE(0)
+    __syncthreads();
+
+    f32x4 acc[4][NT];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nkc = (int)(Ktot / P16_KC);  // = DG
+    const int arow = wave * 64 + l15;
+    for (int kc = 0; kc < nkc; ++kc) {
+        if (kc + 1 < nkc) { P16_WLOAD(kc + 1) }
+        const char* wb = wl + (kc & 1) * WBUF;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int idx = kc * 16 + s * 4 + kgrp;  // 16-byte chunk index along k
+            const int j = idx / CH, cc = idx - j * CH;
+            const char* ap = win + ((size_t)cc * ROWS + arow + j) * 16;
+            uint4 fa[4], fb[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) fb[n] = *(const uint4*)(wb + ((n * 16 + l15) * 16 + ((s * 4 + kgrp) ^ l15)) * 16);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) fa[m] = *(const uint4*)(ap + m * 256);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[m][n] = Mma16x16<T>::run(fa[m], fb[n], acc[m][n]);
+        }
+        if (kc + 1 < nkc) { P16_WSTORE((kc + 1) & 1) }
+        __syncthreads();
+    }
+#undef P16_WLOAD
+#undef P16_WSTORE
+
+    // D layout of 16x16: col = lane&15 (channel), row = 4*(lane>>4) + reg (frame)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int c = g * DG + n * 16 + l15;
+        const float bias = p.bias[c];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int t = t0 + wave * 64 + m * 16 + 4 * kgrp + r;
+                if (t < p.T) {
+                    const long o = ((long)b * p.T + t) * p.D + c;
+                    p.out[o] = p.x[o] + gelu_fast(acc[m][n][r] + bias);
+                }
+            }
+    }
+}
+
+template <typename T, int DG>
+hipError_t pc16_launch(const PosConvParams& p, hipStream_t s) {
+    const int ROWS = (P16_TM + p.K - 1 + 15) & ~15;
+    const size_t lds = (size_t)(DG / 8) * ROWS * 16 + 2 * DG * 256;
+    hipError_t e = hipFuncSetAttribute((const void*)posconv16_kernel<T, DG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    dim3 grid((p.T + P16_TM - 1) / P16_TM, p.G, p.B);
+    hipLaunchKernelGGL((posconv16_kernel<T, DG>), grid, dim3(256), lds, s, p);
+    return hipGetLastError();
+}
+
+template <typename T>
+hipError_t pc16_dispatch(const PosConvParams& p, int dg, hipStream_t s) {
+    switch (dg) {
+        case 32: return pc16_launch<T, 32>(p, s);
+        case 48: return pc16_launch<T, 48>(p, s);
+        case 64: return pc16_launch<T, 64>(p, s);
+    }
+    return hipErrorInvalidValue;
+}
+
 }  // namespace
+
+// 16-bit operand modes: p.w is the 16-bit [G][Dg][K*Dg] pack (k = tap*Dg + ci), x / out stay fp32.
+hipError_t launch_posconv16(int dtype, const PosConvParams& p, hipStream_t s) {
+    if (p.B <= 0 || p.T <= 0) return hipSuccess;
+    const int dg = p.D / p.G;
+    if (dg * p.G != p.D || (p.K & 1) || ((long)p.K * dg) % P16_KC) return hipErrorInvalidValue;
+    if (dtype == BF16) return pc16_dispatch<bf16_tag>(p, dg, s);
+    if (dtype == F16) return pc16_dispatch<f16_tag>(p, dg, s);
+    return hipErrorInvalidValue;
+}
 
 hipError_t launch_posconv(const PosConvParams& p, hipStream_t s) {
     if (p.B <= 0 || p.T <= 0) return hipSuccess;

@@ -237,3 +237,36 @@ def test_attention(dtype, T, rel):
     assert np.isfinite(got).all()
     err = O.rel_err(got, ref)
     assert err < {"fp32": 2e-5, "bf16": 1.5e-2, "fp16": 2e-3}[dtype], f"attention {dtype} T={T}: rel-err {err:.3e}"
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
+@pytest.mark.parametrize("shape", [(2, 499, 768, 16, 128), (1, 300, 1024, 16, 128), (3, 70, 128, 4, 16), (2, 257, 768, 16, 128)])
+def test_posconv(dtype, shape):
+    """Positional conv + GELU + residual (posconv.hip: fp32 Toeplitz kernel and the 16-bit implicit-GEMM kernel) against
+    the oracle's pos_conv on the same (operand-rounded) inputs; Dg = 48 / 64 / 32, tiles with ragged frame counts."""
+    torch = _torch()
+    from s3prl_amd import _lib
+    from types import SimpleNamespace
+
+    lib = _lib.load()
+    B, T, D, G, K = shape
+    Dg = D // G
+    rng = np.random.default_rng(zlib.crc32(f"pc/{dtype}/{shape}".encode()))
+    x = rng.standard_normal((B, T, D)).astype(np.float32)
+    w = (rng.standard_normal((D, Dg, K)) / np.sqrt(Dg * K)).astype(np.float32) * 3.0
+    bias = rng.standard_normal(D).astype(np.float32)
+    # reference in float64 on the operands the kernel sees (16-bit modes round x and w, not the residual)
+    cfg = SimpleNamespace(conv_pos=K, conv_pos_groups=G)
+    xr, wr = _round(x, dtype).astype(np.float64), _round(w, dtype).astype(np.float64)
+    W = {"encoder.pos_conv.0.weight_g": np.sqrt((wr ** 2).sum(axis=(0, 1), keepdims=True)),
+         "encoder.pos_conv.0.weight_v": wr, "encoder.pos_conv.0.bias": bias.astype(np.float64)}
+    ref = x.astype(np.float64) + O.pos_conv(cfg, W, xr)
+    dx, db = _dev(x), _dev(bias)
+    out = torch.full((B, T, D), float("nan"), device="cuda")
+    wh = np.ascontiguousarray(w)
+    rc = lib.s3enc_op_posconv(_lib.DTYPES[dtype], _ptr(dx), wh.ctypes.data_as(C.c_void_p), _ptr(db), B, T, D, G, K, _ptr(out), None)
+    _lib.check(rc, "s3enc_op_posconv")
+    got = out.cpu().numpy()
+    assert np.isfinite(got).all()
+    err = O.rel_err(got - x, ref - x)  # error of the conv branch itself, not hidden behind the residual
+    assert err < TOL[dtype], f"posconv {dtype}/{shape}: rel-err {err:.3e}"
