@@ -163,6 +163,27 @@ int s3enc_op_attention(int32_t dtype, const void* qkv, void* out, const int32_t*
 int s3enc_op_posconv(int32_t dtype, const float* x, const float* w_host, const float* bias, int32_t B, int32_t T, int32_t D,
                      int32_t G, int32_t K, float* out, void* stream);
 
+/* ---- the `fbank` baseline upstream (BASELINE configs[0]) --------------------------------------------------------
+ * Replaces get_extracter(fbank.yaml) + UpstreamExpert.forward of upstream/baseline (extracter.py:32-90,
+ * expert.py:46-79): torchaudio.compliance.kaldi.fbank -> delta, delta-delta -> CMVN over time -> pad_sequence. */
+typedef struct s3enc_fbank_config {
+    int32_t sample_rate;      /* 16000 */
+    int32_t num_mel_bins;     /* 80   (fbank.yaml) */
+    float frame_length_ms;    /* 25 */
+    float frame_shift_ms;     /* 10 */
+    float preemphasis;        /* 0.97 (kaldi default) */
+    int32_t delta_order;      /* 2 */
+    int32_t delta_win_length; /* 5 */
+    int32_t use_cmvn;         /* 1 */
+    float cmvn_eps;           /* 1e-10 (extracter.py:80) */
+} s3enc_fbank_config;
+/* frames of an n-sample utterance (snip_edges): 1 + (n - window) / shift, 0 if shorter than one window */
+int s3enc_fbank_num_frames(const s3enc_fbank_config* cfg, int64_t n_samples, int32_t* frames);
+/* wavs: host array of B device pointers (borrowed); out: device fp32 (B, T_max, num_mel_bins*(delta_order+1)),
+ * zero beyond each utterance's frames (pad_sequence); T_max >= the longest utterance's frame count. */
+int s3enc_fbank_forward(const s3enc_fbank_config* cfg, const float* const* wavs, const int64_t* lengths, int32_t B,
+                        float* out, int64_t T_max, int32_t device, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

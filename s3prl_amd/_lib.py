@@ -40,6 +40,12 @@ class S3ProfileEntry(C.Structure):
                 ("bytes", C.c_double)]
 
 
+class S3FbankConfig(C.Structure):
+    _fields_ = [("sample_rate", C.c_int32), ("num_mel_bins", C.c_int32), ("frame_length_ms", C.c_float),
+                ("frame_shift_ms", C.c_float), ("preemphasis", C.c_float), ("delta_order", C.c_int32),
+                ("delta_win_length", C.c_int32), ("use_cmvn", C.c_int32), ("cmvn_eps", C.c_float)]
+
+
 # every symbol include/s3enc.h declares: (restype, argtypes)
 _VP, _I32, _I64 = C.c_void_p, C.c_int32, C.c_int64
 _PROTOS = {
@@ -63,6 +69,8 @@ _PROTOS = {
     "s3enc_op_layernorm": (C.c_int, [_I32, _VP, _VP, _VP, _I32, _I32, _I32, _VP, _VP, _VP]),
     "s3enc_op_attention": (C.c_int, [_I32, _VP, _VP, _VP, _I32, _I32, _I32, _VP, _VP, _VP]),
     "s3enc_op_posconv": (C.c_int, [_I32, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _VP, _VP]),
+    "s3enc_fbank_num_frames": (C.c_int, [C.POINTER(S3FbankConfig), _I64, C.POINTER(_I32)]),
+    "s3enc_fbank_forward": (C.c_int, [C.POINTER(S3FbankConfig), _VP, C.POINTER(_I64), _I32, _VP, _I64, _I32, _VP]),
 }
 
 _lib = None

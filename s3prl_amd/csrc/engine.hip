@@ -1078,4 +1078,45 @@ int s3enc_op_posconv(int32_t dtype, const float* x, const float* w_host, const f
     return 0;
 }
 
+static FbankParams fbank_params(const s3enc_fbank_config* c) {
+    FbankParams f;
+    f.sample_rate = c->sample_rate;
+    f.num_mel_bins = c->num_mel_bins;
+    f.frame_length_ms = c->frame_length_ms;
+    f.frame_shift_ms = c->frame_shift_ms;
+    f.preemph = c->preemphasis;
+    f.delta_order = c->delta_order;
+    f.delta_win = c->delta_win_length;
+    f.use_cmvn = c->use_cmvn;
+    f.cmvn_eps = c->cmvn_eps;
+    return f;
+}
+
+int s3enc_fbank_num_frames(const s3enc_fbank_config* cfg, int64_t n_samples, int32_t* frames) {
+    if (!cfg || !frames) return fail("s3enc_fbank_num_frames: null argument");
+    *frames = (int32_t)fbank_num_frames(n_samples, fbank_params(cfg));
+    return 0;
+}
+
+int s3enc_fbank_forward(const s3enc_fbank_config* cfg, const float* const* wavs, const int64_t* lengths, int32_t B, float* out,
+                        int64_t T_max, int32_t device, void* stream) {
+    if (!cfg || !wavs || !lengths || !out) return fail("s3enc_fbank_forward: null argument");
+    if (B <= 0) return fail("s3enc_fbank_forward: empty batch");
+    const FbankParams f = fbank_params(cfg);
+    if (f.delta_order < 0 || f.delta_order > 2 || f.delta_win < 3 || !(f.delta_win & 1)) return fail("s3enc_fbank_forward: unsupported delta configuration");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail("s3enc_fbank_forward: no HIP device (there is no CPU fallback)");
+    HIP_TRY(hipSetDevice(device));
+    const int F = f.num_mel_bins * (f.delta_order + 1);
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(out, 0, (size_t)B * T_max * F * sizeof(float), st));
+    for (int b = 0; b < B; ++b) {
+        const long T = fbank_num_frames(lengths[b], f);
+        if (T <= 0) return fail("s3enc_fbank_forward: an utterance is shorter than one analysis window");
+        if (T > T_max) return fail("s3enc_fbank_forward: T_max is smaller than an utterance's frame count");
+        HIP_TRY(launch_fbank(f, wavs[b], lengths[b], out + (size_t)b * T_max * F, F, st));
+    }
+    return 0;
+}
+
 }  // extern "C"

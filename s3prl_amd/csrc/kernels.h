@@ -87,4 +87,18 @@ hipError_t launch_posconv(const PosConvParams& p, hipStream_t s);
 // 16-bit operand modes: p.w = 16-bit pack [G][Dg][K*Dg] with k = tap*Dg + ci; x / out / bias fp32
 hipError_t launch_posconv16(int dtype, const PosConvParams& p, hipStream_t s);
 
+// ---- fbank.hip (the `fbank` baseline upstream, BASELINE configs[0]) -----------------------------------------------
+struct FbankParams {
+    int sample_rate = 16000;
+    int num_mel_bins = 80;
+    float frame_length_ms = 25.f, frame_shift_ms = 10.f;
+    float preemph = 0.97f;
+    int delta_order = 2, delta_win = 5;
+    int use_cmvn = 1;
+    float cmvn_eps = 1e-10f;
+};
+long fbank_num_frames(long n_samples, const FbankParams& c);
+// one utterance: wav (device) -> out (device, frames x ldo), columns [0, num_mel_bins * (delta_order + 1))
+hipError_t launch_fbank(const FbankParams& c, const float* wav, long n, float* out, int ldo, hipStream_t st);
+
 }  // namespace s3

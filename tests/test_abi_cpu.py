@@ -41,14 +41,16 @@ def test_struct_layout_matches_header(tmp_path):
     src.write_text(
         '#include <stdio.h>\n#include <stddef.h>\n#include "s3enc.h"\n'
         'int main(void){printf("%zu %zu %zu %zu %zu\\n", sizeof(s3enc_config), sizeof(s3enc_tensor), '
-        'sizeof(s3enc_profile_entry), offsetof(s3enc_config, compute_dtype), offsetof(s3enc_tensor, shape));return 0;}\n'
+        'sizeof(s3enc_profile_entry), offsetof(s3enc_config, compute_dtype), offsetof(s3enc_tensor, shape));'
+        'printf("%zu %zu\\n", sizeof(s3enc_fbank_config), offsetof(s3enc_fbank_config, cmvn_eps));return 0;}\n'
     )
     exe = tmp_path / "sz"
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)],
                    check=True)
     got = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
     assert got == [C.sizeof(_lib.S3Config), C.sizeof(_lib.S3Tensor), C.sizeof(_lib.S3ProfileEntry),
-                   _lib.S3Config.compute_dtype.offset, _lib.S3Tensor.shape.offset]
+                   _lib.S3Config.compute_dtype.offset, _lib.S3Tensor.shape.offset,
+                   C.sizeof(_lib.S3FbankConfig), _lib.S3FbankConfig.cmvn_eps.offset]
 
 
 def test_no_gpu_means_loud_failure():
