@@ -252,6 +252,7 @@ hipError_t launch_gemm(int dtype, const GemmParams& p0, hipStream_t stream) {
     if (p.variant < 0) p.variant = g_gemm_variant;
     if (p.M <= 0 || p.N <= 0 || p.batches <= 0) return hipSuccess;
     if (gemm16_big_eligible(dtype, p)) return launch_gemm16_big(dtype, p, stream);
+    p.variant &= 7;
     const int eb = dtype == F32 ? 4 : 2;
     // 16-byte vector loads: row starts and K must be 16-byte granular
     if (((p.lda * eb) & 15) || ((p.a_bs * eb) & 15) || (((long)p.K * eb) & 15) || (((uintptr_t)p.A) & 15) ||

@@ -8,6 +8,7 @@ import torch
 from s3prl_amd import _lib
 
 lib = _lib.load()
+CHECK = True
 SHAPES = {  # name: (batches, M, N, K, lda, a_bs_rows)
     "conv1": (32, 15999, 512, 1536, 1024, 31999),
     "conv2": (32, 7999, 512, 1536, 1024, 15999),
@@ -56,7 +57,7 @@ def run(dtype, variants=None, rounds=5, shapes=None, reps=10):
                 o = (out32 if out32 is not None else out16).float()
                 chk = float(o[:: 9973].double().sum())
                 if ref is None: ref = chk
-                assert abs(chk - ref) <= 1e-3 * abs(ref) + 1e-3, (name, v, chk, ref)
+                assert not CHECK or abs(chk - ref) <= 1e-3 * abs(ref) + 1e-3, (name, v, chk, ref)
         fl = 2.0 * nb * M * N * K
         print(f"  {name:9s}", "  ".join(f"v{v}: {min(t):7.3f} ms {fl / min(t) / 1e9:7.1f} TF" for v, t in res.items()))
 
@@ -68,7 +69,11 @@ if __name__ == "__main__":
     ap.add_argument("--variants", default="")
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--probe", type=int, default=0, help="gemm_variant bits for timing probes (8: every tile loads tile 0)")
     a = ap.parse_args()
+    if a.probe:
+        _lib.check(lib.s3enc_set_tuning(b"gemm_variant", a.probe | 1))
+        globals()["CHECK"] = False
     for d in a.dtypes:
         run(d, tuple(int(v) for v in a.variants.split(",")) if a.variants else None, a.rounds,
             set(a.shapes.split(",")) if a.shapes else None, a.reps)
