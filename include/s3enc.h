@@ -163,6 +163,18 @@ int s3enc_op_attention(int32_t dtype, const void* qkv, void* out, const int32_t*
 int s3enc_op_posconv(int32_t dtype, const float* x, const float* w_host, const float* bias, int32_t B, int32_t T, int32_t D,
                      int32_t G, int32_t K, float* out, void* stream);
 
+/* ---- Featurizer: the consumer of hidden_states (next row of the path) --------------------------------
+ * Replaces Featurizer._weighted_sum (s3prl/nn/upstream.py:312-328; upstream/interfaces.py:221-249):
+ *   out = sum_l w[l] * (normalize ? F.layer_norm(h_l, (D,)) : h_l),   w = softmax(weights) computed by the caller.
+ * hs: device fp32, layer l is the (rows, D) block at hs + l*layer_stride (the slab s3enc_forward writes);
+ * w: HOST array of L floats (0 = layer not selected); out: device fp32 (rows, D). */
+int s3enc_weighted_sum(const float* hs, int64_t layer_stride, int32_t L, const float* w, int32_t normalize, int64_t rows,
+                       int32_t D, float* out, void* stream);
+/* Gradient of the above w.r.t. w (the upstream is frozen): grad_w[l] = sum <grad_out, hn_l>; grad_w: device, L floats.
+ * Synchronises (scratch is freed on return). */
+int s3enc_weighted_sum_backward(const float* hs, int64_t layer_stride, int32_t L, int32_t normalize, int64_t rows,
+                                int32_t D, const float* grad_out, float* grad_w, void* stream);
+
 /* ---- the `fbank` baseline upstream (BASELINE configs[0]) --------------------------------------------------------
  * Replaces get_extracter(fbank.yaml) + UpstreamExpert.forward of upstream/baseline (extracter.py:32-90,
  * expert.py:46-79): torchaudio.compliance.kaldi.fbank -> delta, delta-delta -> CMVN over time -> pad_sequence. */

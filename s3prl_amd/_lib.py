@@ -69,6 +69,8 @@ _PROTOS = {
     "s3enc_op_layernorm": (C.c_int, [_I32, _VP, _VP, _VP, _I32, _I32, _I32, _VP, _VP, _VP]),
     "s3enc_op_attention": (C.c_int, [_I32, _VP, _VP, _VP, _I32, _I32, _I32, _VP, _VP, _VP]),
     "s3enc_op_posconv": (C.c_int, [_I32, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _VP, _VP]),
+    "s3enc_weighted_sum": (C.c_int, [_VP, _I64, _I32, C.POINTER(C.c_float), _I32, _I64, _I32, _VP, _VP]),
+    "s3enc_weighted_sum_backward": (C.c_int, [_VP, _I64, _I32, _I32, _I64, _I32, _VP, _VP, _VP]),
     "s3enc_fbank_num_frames": (C.c_int, [C.POINTER(S3FbankConfig), _I64, C.POINTER(_I32)]),
     "s3enc_fbank_forward": (C.c_int, [C.POINTER(S3FbankConfig), _VP, C.POINTER(_I64), _I32, _VP, _I64, _I32, _VP]),
 }

@@ -70,6 +70,10 @@ __device__ __forceinline__ float gelu_fast(float x) {
     return 0.5f * x * (1.0f + erf);
 }
 
+// GELU of the compute mode: libm-exact erf for the fp32 path, the fast erf for the 16-bit operand modes
+template <typename T> __device__ __forceinline__ float gelu_mode(float x) { return gelu_fast(x); }
+template <> __device__ __forceinline__ float gelu_mode<float>(float x) { return gelu_erf(x); }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

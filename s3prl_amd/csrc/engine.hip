@@ -1078,6 +1078,28 @@ int s3enc_op_posconv(int32_t dtype, const float* x, const float* w_host, const f
     return 0;
 }
 
+int s3enc_weighted_sum(const float* hs, int64_t layer_stride, int32_t L, const float* w, int32_t normalize, int64_t rows, int32_t D,
+                       float* out, void* stream) {
+    if (!hs || !w || !out) return fail("s3enc_weighted_sum: null argument");
+    if (L <= 0 || L > S3_WS_MAX_LAYERS) return fail("s3enc_weighted_sum: 1..32 layers");
+    if (D <= 0 || (D & 3) || D > 2048) return fail("s3enc_weighted_sum: D must be a multiple of 4, <= 2048");
+    HIP_TRY(launch_weighted_sum(hs, layer_stride, L, w, normalize, rows, D, out, (hipStream_t)stream));
+    return 0;
+}
+
+int s3enc_weighted_sum_backward(const float* hs, int64_t layer_stride, int32_t L, int32_t normalize, int64_t rows, int32_t D,
+                                const float* grad_out, float* grad_w, void* stream) {
+    if (!hs || !grad_out || !grad_w) return fail("s3enc_weighted_sum_backward: null argument");
+    if (L <= 0 || L > S3_WS_MAX_LAYERS) return fail("s3enc_weighted_sum_backward: 1..32 layers");
+    if (D <= 0 || (D & 3) || D > 2048) return fail("s3enc_weighted_sum_backward: D must be a multiple of 4, <= 2048");
+    if (rows <= 0) return fail("s3enc_weighted_sum_backward: no rows");
+    DevBuf part;
+    HIP_TRY(part.ensure((size_t)weighted_sum_bwd_blocks(rows) * L * sizeof(double)));
+    HIP_TRY(launch_weighted_sum_bwd(hs, layer_stride, L, normalize, rows, D, grad_out, (double*)part.p, grad_w, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return 0;
+}
+
 static FbankParams fbank_params(const s3enc_fbank_config* c) {
     FbankParams f;
     f.sample_rate = c->sample_rate;

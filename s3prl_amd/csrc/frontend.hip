@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void conv0_kernel(Conv0Params p) {
 #pragma unroll
             for (int g = 0; g < NG; ++g)
 #pragma unroll
-                for (int u = 0; u < 4; ++u) v[g][u] = gelu_erf(fmaf(v[g][u], a0[g][u], a1[g][u]));
+                for (int u = 0; u < 4; ++u) v[g][u] = gelu_mode<T>(fmaf(v[g][u], a0[g][u], a1[g][u]));
         } else {
             // Fp32LayerNorm over the C channels of this frame (wav2vec2_model.py:2887-2897), two-pass
             float s = 0.f;
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void conv0_kernel(Conv0Params p) {
 #pragma unroll
             for (int g = 0; g < NG; ++g)
 #pragma unroll
-                for (int u = 0; u < 4; ++u) v[g][u] = gelu_erf((v[g][u] - mu) * rs * a0[g][u] + a1[g][u]);
+                for (int u = 0; u < 4; ++u) v[g][u] = gelu_mode<T>((v[g][u] - mu) * rs * a0[g][u] + a1[g][u]);
         }
         store_t* o = (store_t*)p.out + ((long)b * p.L0 + t) * p.C;
 #pragma unroll

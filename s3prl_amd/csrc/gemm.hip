@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256, ROWB == 128 ? 2 : 3) void gemm_kernel(GemmPara
                 const int m = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (m >= p.M) continue;
                 float v = acc[i][j][r] + bias;
-                if (p.act) v = gelu_erf(v);
+                if (p.act) v = gelu_mode<T>(v);
                 const long o = ob + (long)m * p.ldo + n;
                 if (p.residual) v += p.residual[o];
                 if (m >= limit) v = 0.f;

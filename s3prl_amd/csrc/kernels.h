@@ -87,6 +87,17 @@ hipError_t launch_posconv(const PosConvParams& p, hipStream_t s);
 // 16-bit operand modes: p.w = 16-bit pack [G][Dg][K*Dg] with k = tap*Dg + ci; x / out / bias fp32
 hipError_t launch_posconv16(int dtype, const PosConvParams& p, hipStream_t s);
 
+// ---- featurizer.hip (weighted sum over layers, the consumer of hidden_states) ---------------------
+#define S3_WS_MAX_LAYERS 32
+// out[row] = sum_l w[l] * (normalize ? layer_norm(hs[l][row]) : hs[l][row]);  w: HOST array (softmax already applied,
+// 0 for unselected layers); hs[l] at hs + l*layer_stride, rows x D fp32
+hipError_t launch_weighted_sum(const float* hs, long layer_stride, int L, const float* w_host, int normalize, long rows, int D,
+                               float* out, hipStream_t st);
+// grad_w[l] = sum <grad_out, hn_l>;  partial: device scratch of weighted_sum_bwd_blocks(rows) * L doubles
+int weighted_sum_bwd_blocks(long rows);
+hipError_t launch_weighted_sum_bwd(const float* hs, long layer_stride, int L, int normalize, long rows, int D,
+                                   const float* grad_out, double* partial, float* grad_w, hipStream_t st);
+
 // ---- fbank.hip (the `fbank` baseline upstream, BASELINE configs[0]) -----------------------------------------------
 struct FbankParams {
     int sample_rate = 16000;

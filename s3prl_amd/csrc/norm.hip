@@ -51,10 +51,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
         y.z = (v[i].z - mu) * rs * g.z + bt.z;
         y.w = (v[i].w - mu) * rs * g.w + bt.w;
         if (act) {
-            y.x = gelu_erf(y.x);
-            y.y = gelu_erf(y.y);
-            y.z = gelu_erf(y.z);
-            y.w = gelu_erf(y.w);
+            y.x = gelu_mode<T>(y.x);
+            y.y = gelu_mode<T>(y.y);
+            y.z = gelu_mode<T>(y.z);
+            y.w = gelu_mode<T>(y.w);
         }
         if (out32) *(float4*)(out32 + row * C + 4 * ch) = y;
         if (out16) {

@@ -79,3 +79,51 @@ def test_shard_bounds_cover_batch():
                 assert 0 <= e - b <= per
                 seen += list(range(b, e))
             assert seen == list(range(B))
+
+
+def _worker_feat(rank, world, port, lengths, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import encoder_oracle as O
+    from s3prl_amd.parallel import featurize_data_parallel
+    from s3prl_amd.synth import named_config, synth_wavs, synth_weights
+
+    cfg = named_config("tiny_hubert")
+    weights = synth_weights(cfg, 1)
+    wavs = [torch.from_numpy(w) for w in synth_wavs(lengths, 11)]
+    lw = torch.softmax(torch.linspace(-1, 1, cfg.encoder_layers + 1), 0)
+
+    def encode_fn(shard, n_max):
+        return torch.from_numpy(np.stack(O.forward(cfg, weights, [w.numpy() for w in shard], dtype=np.float32, n_max=n_max)))
+
+    feat = featurize_data_parallel(encode_fn, lambda hs: (lw.view(-1, 1, 1, 1) * hs).sum(0), wavs)
+    ret.put((rank, feat.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_featurize_before_gather_equals_full_batch():
+    """§8f-1: weighted sum on the shard, then ONE all-gather of (B, T, D) — same result as featurizing the full batch."""
+    from oracle import encoder_oracle as O
+    from s3prl_amd.synth import named_config, synth_wavs, synth_weights
+
+    world, lengths = 2, [4000, 2345, 3111]
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker_feat, args=(r, world, port, lengths, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(ret.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    cfg = named_config("tiny_hubert")
+    full = np.stack(O.forward(cfg, synth_weights(cfg, 1), synth_wavs(lengths, 11), dtype=np.float32))
+    lw = torch.softmax(torch.linspace(-1, 1, cfg.encoder_layers + 1), 0).numpy()
+    ref = (lw[:, None, None, None] * full).sum(0)
+    for r in range(world):
+        assert results[r].shape == ref.shape
+        assert O.rel_err(results[r], ref) < 1e-5
