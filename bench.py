@@ -75,6 +75,9 @@ def main():
     ap.add_argument("--model", default="hubert_base")
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
     ap.add_argument("--secs", type=float, default=10.0)
+    ap.add_argument("--mixed", action="store_true",
+                    help="mixed-length batch (BASELINE configs[4] recipe): utterance 0 has --secs, the rest "
+                         "randint(1 s, --secs), seed 1234; frames are counted per utterance (sum of T_i)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=32, help="utterances of the workload timed on the CPU oracle")
     ap.add_argument("--parity-sample", type=int, default=2, help="utterances checked against the numpy oracle")
@@ -112,8 +115,13 @@ def main():
     n = int(args.secs * 16000)
     B = args.batch
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-    wavs = [torch.randn(n, device=dev, generator=gen) for _ in range(B)]
+    lens = [n] * B
+    if args.mixed:
+        rng = np.random.default_rng(1234 + rank)
+        lens = [n] + [int(x) for x in rng.integers(16000, n, size=B - 1)]
+    wavs = [torch.randn(m, device=dev, generator=gen) for m in lens]
     T = enc.num_frames(n)
+    frames_per_batch = sum(enc.num_frames(m) for m in lens)
     NL, D = cfg.encoder_layers, cfg.encoder_embed_dim
     out = torch.empty((NL + 1, B, T, D), dtype=torch.float32, device=dev)
     gathered = torch.empty((NL + 1, world * B, T, D), dtype=torch.float32, device=dev) if world > 1 else None
@@ -154,7 +162,7 @@ def main():
     prof = enc.profile_read()
 
     if rank == 0:
-        frames = world * B * T * args.steps
+        frames = world * frames_per_batch * args.steps
         ms_per_step = elapsed / args.steps * 1e3
         value = frames / elapsed
         gem = [p for p in prof if p["name"].startswith("gemm:")]
@@ -182,7 +190,9 @@ def main():
                 "workload": f"{args.model} random-init, {B}x{args.secs:g} s @16 kHz per GPU, all {NL + 1} hidden_states "
                             f"(fp32) written; per-layer RCCL all-gather across {world} GPU(s)",
                 "utterances_per_gpu": B, "samples": n, "frames_per_utt": T, "parallelism": f"dp{world}",
+                "lengths": "mixed (utt 0 = max, rest randint(16000, max), padding-masked)" if args.mixed else "equal",
             },
+            # the reference computes padded frames too, so the path's work is B x F_utt(n_max)
             "path_tflops": round(world * B * flops_per_utt(cfg, n) / (ms_per_step * 1e-3) / 1e12, 2),
             "roofline": {
                 "kernel": "gemm_kernel (conv1-6 implicit GEMM + proj/qkv/out_proj/fc1/fc2)",
@@ -203,6 +213,8 @@ def main():
             from oracle import torch_oracle as TO
 
             ns = max(1, min(args.cpu_sample, B))
+            if args.mixed:
+                raise SystemExit("--mixed: pass --no-cpu-baseline (the CPU sample assumes equal lengths)")
             Wt = TO.prepare(cfg, weights)
             sample = [w.cpu() for w in wavs[:ns]]
             # the reference's recipe is set_num_threads(os.cpu_count()); on a many-core host that oversubscribes oneDNN

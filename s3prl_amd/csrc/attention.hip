@@ -207,40 +207,52 @@ __global__ __launch_bounds__(256) void attn_h16_kernel(AttnParams p) {
             const uint4 kf = *(const uint4*)(Ks + l31 * KS16 + st * 16 + 8 * half);
             s = Mma16<T>::run(kf, qf[st], s);
         }
-        float mx = -INFINITY;
+        // VALU, not the matrix pipe, bounds this kernel at the 16-bit MFMA rate, so the softmax is kept lean:
+        // bias / mask passes only where they apply, and the running max is only raised (and O, l rescaled) when some
+        // query's tile max exceeds it by more than 8 — softmax is invariant to the reference point, e^8 fits every
+        // operand type, and after the first tile the rescale of the 32 O registers is almost never needed.
+        if (btab) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = kt * KT + crow(r, half);
-            float v = s[r];
-            if (btab && key < p.T) v += gate * btab[key - q_c + p.T - 1];
-            v = key < valid ? v : -INFINITY;
-            s[r] = v;
-            mx = fmaxf(mx, v);
+            for (int r = 0; r < 16; ++r) {
+                const int key = kt * KT + crow(r, half);
+                if (key < p.T) s[r] += gate * btab[key - q_c + p.T - 1];
+            }
         }
+        if (kt * KT + KT > valid) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = kt * KT + crow(r, half) < valid ? s[r] : -INFINITY;
+        }
+        float mx = s[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __expf(m_run - m_new);
+        if (__any(mx > m_run + 8.f)) {
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * 1.44269504088896340736f);
+            l_run *= alpha;
+            m_run = m_new;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                o0[r] *= alpha;
+                o1[r] *= alpha;
+            }
+        }
+        const float mneg = -m_run * 1.44269504088896340736f;
         float ps = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            s[r] = __expf(s[r] - m_new);
+            s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], 1.44269504088896340736f, mneg));
             ps += s[r];
         }
-        l_run = l_run * alpha + ps;
-        m_run = m_new;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            o0[r] *= alpha;
-            o1[r] *= alpha;
-        }
+        l_run += ps;
         // P^T as B operand: step u uses regs 8u..8u+7  <->  keys 16u + {0,1,2,3,8,9,10,11} + 4*half
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             uint4 pf;
-            pf.x = (unsigned)Cvt<T>::to(s[8 * u + 0]) | ((unsigned)Cvt<T>::to(s[8 * u + 1]) << 16);
-            pf.y = (unsigned)Cvt<T>::to(s[8 * u + 2]) | ((unsigned)Cvt<T>::to(s[8 * u + 3]) << 16);
-            pf.z = (unsigned)Cvt<T>::to(s[8 * u + 4]) | ((unsigned)Cvt<T>::to(s[8 * u + 5]) << 16);
-            pf.w = (unsigned)Cvt<T>::to(s[8 * u + 6]) | ((unsigned)Cvt<T>::to(s[8 * u + 7]) << 16);
+            pf.x = Cvt<T>::pack2(s[8 * u + 0], s[8 * u + 1]);
+            pf.y = Cvt<T>::pack2(s[8 * u + 2], s[8 * u + 3]);
+            pf.z = Cvt<T>::pack2(s[8 * u + 4], s[8 * u + 5]);
+            pf.w = Cvt<T>::pack2(s[8 * u + 6], s[8 * u + 7]);
             const u16* v0 = Vt + l31 * VS16 + 16 * u + 4 * half;
             const u16* v1 = v0 + 32 * VS16;
             const uint2 a00 = *(const uint2*)(v0), a01 = *(const uint2*)(v0 + 8);

@@ -11,6 +11,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 enum DType : int { F32 = 0, BF16 = 1, F16 = 2 };
 
@@ -21,12 +24,8 @@ constexpr float LN_EPS = 1e-5f;
 struct bf16_tag {};
 struct f16_tag {};
 
-__device__ __forceinline__ u16 f32_to_bf16(float f) {
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (u16)((u >> 16) | 0x40);  // NaN
-    u += 0x7fffu + ((u >> 16) & 1u);  // round to nearest even
-    return (u16)(u >> 16);
-}
+// fp32 -> bf16, round to nearest even: one v_cvt_pk_bf16_f32 on gfx950 (the host packer h_bf16 rounds identically)
+__device__ __forceinline__ u16 f32_to_bf16(float f) { return __builtin_bit_cast(u16, (__bf16)f); }
 __device__ __forceinline__ float bf16_to_f32(u16 h) { return __uint_as_float(((unsigned)h) << 16); }
 __device__ __forceinline__ u16 f32_to_f16(float f) {
     _Float16 h = (_Float16)f;
@@ -43,11 +42,18 @@ template <> struct Cvt<float> {
 template <> struct Cvt<bf16_tag> {
     typedef u16 store_t;
     static __device__ __forceinline__ u16 to(float f) { return f32_to_bf16(f); }
+    // two values -> one packed dword (a in the low half): a single v_cvt_pk_bf16_f32
+    static __device__ __forceinline__ unsigned pack2(float a, float b) {
+        return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a, b}, bf16x2));
+    }
     static __device__ __forceinline__ float from(u16 h) { return bf16_to_f32(h); }
 };
 template <> struct Cvt<f16_tag> {
     typedef u16 store_t;
     static __device__ __forceinline__ u16 to(float f) { return f32_to_f16(f); }
+    static __device__ __forceinline__ unsigned pack2(float a, float b) {
+        return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a, b}, f16x2));
+    }
     static __device__ __forceinline__ float from(u16 h) { return f16_to_f32(h); }
 };
 

@@ -238,9 +238,7 @@ __global__ __launch_bounds__(512, WPE) void gemm16_big_kernel(GemmParams p) {
                 if (m >= limit) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (p.out32) *(float4*)(p.out32 + o) = v;
                 if (p.out16) {
-                    ushort4 h;
-                    h.x = Cvt<T>::to(v.x); h.y = Cvt<T>::to(v.y); h.z = Cvt<T>::to(v.z); h.w = Cvt<T>::to(v.w);
-                    *(ushort4*)((store_t*)p.out16 + o) = h;
+                    *(uint2*)((store_t*)p.out16 + o) = make_uint2(Cvt<T>::pack2(v.x, v.y), Cvt<T>::pack2(v.z, v.w));
                 }
             }
         }

@@ -186,10 +186,10 @@ __global__ __launch_bounds__(256) void posconv16_kernel(PosConvParams p) {
         if (f < rows && ts >= 0 && ts < p.T) {
             const float4 v0 = *(const float4*)(xg + (long)ts * p.D + cc * 8);
             const float4 v1 = *(const float4*)(xg + (long)ts * p.D + cc * 8 + 4);
-            h.x = (unsigned)Cvt<T>::to(v0.x) | ((unsigned)Cvt<T>::to(v0.y) << 16);
-            h.y = (unsigned)Cvt<T>::to(v0.z) | ((unsigned)Cvt<T>::to(v0.w) << 16);
-            h.z = (unsigned)Cvt<T>::to(v1.x) | ((unsigned)Cvt<T>::to(v1.y) << 16);
-            h.w = (unsigned)Cvt<T>::to(v1.z) | ((unsigned)Cvt<T>::to(v1.w) << 16);
+            h.x = Cvt<T>::pack2(v0.x, v0.y);
+            h.y = Cvt<T>::pack2(v0.z, v0.w);
+            h.z = Cvt<T>::pack2(v1.x, v1.y);
+            h.w = Cvt<T>::pack2(v1.z, v1.w);
         }
         *(uint4*)(win + ((size_t)cc * ROWS + f) * 16) = h;
     }
