@@ -56,7 +56,15 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnParams p) {
             qf[4 * i + 3] = t.w;
         }
     }
-    const float* btab = p.bias_table ? p.bias_table + (long)head * (2 * p.T - 1) : nullptr;
+    // WavLM: this head's (2T-1)-entry relative-position table is gathered once per workgroup into LDS — every score
+    // element needs table[(key - query) + T - 1], and a per-element global gather would bound the kernel
+    extern __shared__ float bias_s[];
+    const float* btab = nullptr;
+    if (p.bias_table) {
+        const float* src = p.bias_table + (long)head * (2 * p.T - 1);
+        for (int i = threadIdx.x; i < 2 * p.T - 1; i += 256) bias_s[i] = src[i];
+        btab = bias_s;  // made visible by the first __syncthreads() of the key loop
+    }
     const float gate = (btab && p.gate) ? p.gate[((long)b * p.H + head) * p.T + q_c] : 1.f;
 
     f32x16 o0, o1;
@@ -138,8 +146,13 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnParams p) {
 }
 
 // ---- 16-bit operands ------------------------------------------------------------------------------------------
-constexpr int KS16 = HD + 8;   // u16 per K row: 144 B rows -> conflict-free ds_read_b128
-constexpr int VS16 = KT + 4;   // u16 per V^T row: 72 B rows -> conflict-free ds_read_b64
+// 64 keys per tile, K and V^T double-buffered in LDS, the next tile's global loads in flight (registers) while the
+// current one is multiplied: one barrier per 64 keys.  V is transposed on the way into LDS two keys at a time
+// (32-bit writes of a key pair per dim), so the A operand of O^T += V^T P^T is read as 8-byte vectors.
+constexpr int KT16 = 64;         // keys per tile
+constexpr int KS16 = HD + 8;     // u16 per K row: 144 B rows -> conflict-free ds_read_b128
+constexpr int VS16 = KT16 + 4;   // u16 per V^T row: 136 B rows -> conflict-free ds_read_b64
+constexpr int KBUF16 = KT16 * KS16, VBUF16 = HD * VS16;
 
 template <typename T> struct Mma16;
 template <> struct Mma16<bf16_tag> {
@@ -155,8 +168,8 @@ template <> struct Mma16<f16_tag> {
 
 template <typename T>
 __global__ __launch_bounds__(256) void attn_h16_kernel(AttnParams p) {
-    __shared__ __attribute__((aligned(16))) u16 Ks[KT * KS16];
-    __shared__ __attribute__((aligned(16))) u16 Vt[HD * VS16];
+    __shared__ __attribute__((aligned(16))) u16 Ks[2 * KBUF16];
+    __shared__ __attribute__((aligned(16))) u16 Vt[2 * VBUF16];
     const int b = blockIdx.z, head = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
@@ -171,7 +184,15 @@ __global__ __launch_bounds__(256) void attn_h16_kernel(AttnParams p) {
 #pragma unroll
     for (int st = 0; st < 4; ++st) qf[st] = *(const uint4*)(base + (long)q_c * ld + st * 16 + 8 * half);
 
-    const float* btab = p.bias_table ? p.bias_table + (long)head * (2 * p.T - 1) : nullptr;
+    // WavLM: this head's (2T-1)-entry relative-position table is gathered once per workgroup into LDS — every score
+    // element needs table[(key - query) + T - 1], and a per-element global gather would bound the kernel
+    extern __shared__ float bias_s[];
+    const float* btab = nullptr;
+    if (p.bias_table) {
+        const float* src = p.bias_table + (long)head * (2 * p.T - 1);
+        for (int i = threadIdx.x; i < 2 * p.T - 1; i += 256) bias_s[i] = src[i];
+        btab = bias_s;  // made visible by the first __syncthreads() of the key loop
+    }
     const float gate = (btab && p.gate) ? p.gate[((long)b * p.H + head) * p.T + q_c] : 1.f;
 
     f32x16 o0, o1;
@@ -180,32 +201,51 @@ __global__ __launch_bounds__(256) void attn_h16_kernel(AttnParams p) {
     float m_run = -INFINITY, l_run = 0.f;
 
     const int valid = p.valid[b];
-    const int ntiles = (valid + KT - 1) / KT;
-    const int srow = tid >> 3, sc8 = tid & 7;  // staging: key row, 8-element column group
-    for (int kt = 0; kt < ntiles; ++kt) {
-        __syncthreads();
-        {
-            int kr = kt * KT + srow;
-            kr = kr < p.T ? kr : p.T - 1;
-            const u16* src = base + (long)kr * ld + sc8 * 8;
-            *(uint4*)(Ks + srow * KS16 + sc8 * 8) = *(const uint4*)(src + D);
-            const uint4 vv = *(const uint4*)(src + 2 * D);
-            const unsigned w[4] = {vv.x, vv.y, vv.z, vv.w};
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                Vt[(sc8 * 8 + 2 * i) * VS16 + srow] = (u16)(w[i] & 0xffffu);
-                Vt[(sc8 * 8 + 2 * i + 1) * VS16 + srow] = (u16)(w[i] >> 16);
-            }
-        }
-        __syncthreads();
+    const int ntiles = (valid + KT16 - 1) / KT16;
+    // staging roles: K — rows (tid>>3) and +32, 16-byte chunk tid&7;  V — key pair tid&31, dim group tid>>5
+    const int krow = tid >> 3, kc8 = tid & 7;
+    const int vj = tid & 31, vdg = tid >> 5;
+    u32x4 kreg[2], vreg[2];
+    auto clampk = [&](int kr) { return kr < p.T ? kr : p.T - 1; };
+#define A16_LOAD(kt_)                                                                               \
+    {                                                                                               \
+        const int k0_ = (kt_) * KT16;                                                               \
+        kreg[0] = *(const u32x4*)(base + (long)clampk(k0_ + krow) * ld + D + kc8 * 8);              \
+        kreg[1] = *(const u32x4*)(base + (long)clampk(k0_ + krow + 32) * ld + D + kc8 * 8);         \
+        vreg[0] = *(const u32x4*)(base + (long)clampk(k0_ + 2 * vj) * ld + 2 * D + vdg * 8);        \
+        vreg[1] = *(const u32x4*)(base + (long)clampk(k0_ + 2 * vj + 1) * ld + 2 * D + vdg * 8);    \
+    }
+#define A16_STORE(buf_)                                                                             \
+    {                                                                                               \
+        u16* ks_ = Ks + (buf_) * KBUF16;                                                            \
+        u16* vt_ = Vt + (buf_) * VBUF16;                                                            \
+        *(u32x4*)(ks_ + krow * KS16 + kc8 * 8) = kreg[0];                                           \
+        *(u32x4*)(ks_ + (krow + 32) * KS16 + kc8 * 8) = kreg[1];                                    \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                          \
+            const unsigned a_ = vreg[0][i_], b_ = vreg[1][i_];                                      \
+            *(unsigned*)(vt_ + (vdg * 8 + 2 * i_) * VS16 + 2 * vj) = (a_ & 0xffffu) | (b_ << 16);   \
+            *(unsigned*)(vt_ + (vdg * 8 + 2 * i_ + 1) * VS16 + 2 * vj) = (a_ >> 16) | (b_ & 0xffff0000u); \
+        }                                                                                           \
+    }
+    A16_LOAD(0)
+    A16_STORE(0)
+    __syncthreads();
 
-        f32x16 s;
+    for (int kt = 0; kt < ntiles; ++kt) {
+        if (kt + 1 < ntiles) A16_LOAD(kt + 1)
+        const u16* ks = Ks + (kt & 1) * KBUF16;
+        const u16* vt = Vt + (kt & 1) * VBUF16;
+
+        f32x16 s[2];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+        for (int h = 0; h < 2; ++h) {
 #pragma unroll
-        for (int st = 0; st < 4; ++st) {
-            const uint4 kf = *(const uint4*)(Ks + l31 * KS16 + st * 16 + 8 * half);
-            s = Mma16<T>::run(kf, qf[st], s);
+            for (int r = 0; r < 16; ++r) s[h][r] = 0.f;
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const uint4 kf = *(const uint4*)(ks + (h * 32 + l31) * KS16 + st * 16 + 8 * half);
+                s[h] = Mma16<T>::run(kf, qf[st], s[h]);
+            }
         }
         // VALU, not the matrix pipe, bounds this kernel at the 16-bit MFMA rate, so the softmax is kept lean:
         // bias / mask passes only where they apply, and the running max is only raised (and O, l rescaled) when some
@@ -213,18 +253,22 @@ __global__ __launch_bounds__(256) void attn_h16_kernel(AttnParams p) {
         // operand type, and after the first tile the rescale of the 32 O registers is almost never needed.
         if (btab) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kt * KT + crow(r, half);
-                if (key < p.T) s[r] += gate * btab[key - q_c + p.T - 1];
-            }
-        }
-        if (kt * KT + KT > valid) {
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] = kt * KT + crow(r, half) < valid ? s[r] : -INFINITY;
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kt * KT16 + h * 32 + crow(r, half);
+                    if (key < p.T) s[h][r] += gate * btab[key - q_c + p.T - 1];
+                }
         }
-        float mx = s[0];
+        if (kt * KT16 + KT16 > valid) {
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[h][r] = kt * KT16 + h * 32 + crow(r, half) < valid ? s[h][r] : -INFINITY;
+        }
+        float mx = fmaxf(s[0][0], s[1][0]);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s[0][r], s[1][r]));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         if (__any(mx > m_run + 8.f)) {
             const float m_new = fmaxf(m_run, mx);
@@ -240,72 +284,88 @@ __global__ __launch_bounds__(256) void attn_h16_kernel(AttnParams p) {
         const float mneg = -m_run * 1.44269504088896340736f;
         float ps = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], 1.44269504088896340736f, mneg));
-            ps += s[r];
-        }
-        l_run += ps;
-        // P^T as B operand: step u uses regs 8u..8u+7  <->  keys 16u + {0,1,2,3,8,9,10,11} + 4*half
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+            for (int r = 0; r < 16; ++r) {
+                s[h][r] = __builtin_amdgcn_exp2f(fmaf(s[h][r], 1.44269504088896340736f, mneg));
+                ps += s[h][r];
+            }
+        l_run += ps;
+        // P^T as B operand: step u uses regs 8(u&1)..+7 of s[u>>1]  <->  keys 16u + {0,1,2,3,8,9,10,11} + 4*half
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const f32x16& sv = s[u >> 1];
+            const int r0 = 8 * (u & 1);
             uint4 pf;
-            pf.x = Cvt<T>::pack2(s[8 * u + 0], s[8 * u + 1]);
-            pf.y = Cvt<T>::pack2(s[8 * u + 2], s[8 * u + 3]);
-            pf.z = Cvt<T>::pack2(s[8 * u + 4], s[8 * u + 5]);
-            pf.w = Cvt<T>::pack2(s[8 * u + 6], s[8 * u + 7]);
-            const u16* v0 = Vt + l31 * VS16 + 16 * u + 4 * half;
+            pf.x = Cvt<T>::pack2(sv[r0 + 0], sv[r0 + 1]);
+            pf.y = Cvt<T>::pack2(sv[r0 + 2], sv[r0 + 3]);
+            pf.z = Cvt<T>::pack2(sv[r0 + 4], sv[r0 + 5]);
+            pf.w = Cvt<T>::pack2(sv[r0 + 6], sv[r0 + 7]);
+            const u16* v0 = vt + l31 * VS16 + 16 * u + 4 * half;
             const u16* v1 = v0 + 32 * VS16;
             const uint2 a00 = *(const uint2*)(v0), a01 = *(const uint2*)(v0 + 8);
             const uint2 a10 = *(const uint2*)(v1), a11 = *(const uint2*)(v1 + 8);
             o0 = Mma16<T>::run(make_uint4(a00.x, a00.y, a01.x, a01.y), pf, o0);
             o1 = Mma16<T>::run(make_uint4(a10.x, a10.y, a11.x, a11.y), pf, o1);
         }
+        if (kt + 1 < ntiles) A16_STORE((kt + 1) & 1)
+        __syncthreads();
     }
+#undef A16_LOAD
+#undef A16_STORE
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.f / l_tot;
     if (q_g < p.T) {
         u16* op = (u16*)p.out + ((long)b * p.T + q_g) * D + head * HD + 4 * half;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            ushort4 h0, h1;
-            h0.x = Cvt<T>::to(o0[4 * g] * inv);
-            h0.y = Cvt<T>::to(o0[4 * g + 1] * inv);
-            h0.z = Cvt<T>::to(o0[4 * g + 2] * inv);
-            h0.w = Cvt<T>::to(o0[4 * g + 3] * inv);
-            h1.x = Cvt<T>::to(o1[4 * g] * inv);
-            h1.y = Cvt<T>::to(o1[4 * g + 1] * inv);
-            h1.z = Cvt<T>::to(o1[4 * g + 2] * inv);
-            h1.w = Cvt<T>::to(o1[4 * g + 3] * inv);
-            *(ushort4*)(op + 8 * g) = h0;
-            *(ushort4*)(op + 32 + 8 * g) = h1;
+            *(uint2*)(op + 8 * g) = make_uint2(Cvt<T>::pack2(o0[4 * g] * inv, o0[4 * g + 1] * inv),
+                                               Cvt<T>::pack2(o0[4 * g + 2] * inv, o0[4 * g + 3] * inv));
+            *(uint2*)(op + 32 + 8 * g) = make_uint2(Cvt<T>::pack2(o1[4 * g] * inv, o1[4 * g + 1] * inv),
+                                                    Cvt<T>::pack2(o1[4 * g + 2] * inv, o1[4 * g + 3] * inv));
         }
     }
 }
 
 // WavLM gate from the layer input split into heads (wavlm/modules.py:535-549):
 //   g = sigmoid( sum4( grep_linear(x_head) ) ) -> (a, b);  gate = a * (b * grep_a[h] - 1) + 2
+// One wavefront per (b, t) row: the D floats are read once as coalesced float4s (16 lanes per head), the four summed
+// grep_linear outputs of each gate half are ONE dot product with the summed weight rows (sum_o (W_o x + b_o) =
+// (sum_o W_o) x + sum_o b_o), reduced over the head's 16 lanes with four shuffles.
 __global__ __launch_bounds__(256) void wavlm_gate_kernel(const float* x, const float* gw, const float* gb, const float* ga,
                                                          int B, int T, int H, float* gate) {
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;  // over B*T*H
-    const long total = (long)B * T * H;
-    if (idx >= total) return;
-    const int h = (int)(idx % H);
-    const long bt = idx / H;
-    const float* xr = x + bt * (long)H * HD + h * HD;
-    float acc[8];
+    const int lane = threadIdx.x & 63;
+    const long bt = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (bt >= (long)B * T) return;
+    const int k4 = (lane & 15) * 4;  // this lane's 4 dims of its head
+    float wa[4], wb[4];
 #pragma unroll
-    for (int o = 0; o < 8; ++o) acc[o] = gb[o];
-    for (int k = 0; k < HD; ++k) {
-        const float xv = xr[k];
-#pragma unroll
-        for (int o = 0; o < 8; ++o) acc[o] = fmaf(gw[o * HD + k], xv, acc[o]);
+    for (int i = 0; i < 4; ++i) {
+        wa[i] = (gw[0 * HD + k4 + i] + gw[1 * HD + k4 + i]) + (gw[2 * HD + k4 + i] + gw[3 * HD + k4 + i]);
+        wb[i] = (gw[4 * HD + k4 + i] + gw[5 * HD + k4 + i]) + (gw[6 * HD + k4 + i] + gw[7 * HD + k4 + i]);
     }
-    const float sa = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-    const float sb = (acc[4] + acc[5]) + (acc[6] + acc[7]);
-    const float a = 1.f / (1.f + __expf(-sa));
-    const float bb = 1.f / (1.f + __expf(-sb));
+    const float ba = (gb[0] + gb[1]) + (gb[2] + gb[3]), bb0 = (gb[4] + gb[5]) + (gb[6] + gb[7]);
+    const float4* xr = (const float4*)(x + bt * (long)H * HD);
     const int b = (int)(bt / T), t = (int)(bt % T);
-    gate[((long)b * H + h) * T + t] = a * (bb * ga[h] - 1.f) + 2.f;
+    for (int h0 = 0; h0 < H; h0 += 4) {  // 4 heads per round of 64 lanes
+        const int h = h0 + (lane >> 4);
+        float sa = 0.f, sb = 0.f;
+        if (h < H) {
+            const float4 v = xr[h0 * 16 + lane];
+            sa = v.x * wa[0] + v.y * wa[1] + v.z * wa[2] + v.w * wa[3];
+            sb = v.x * wb[0] + v.y * wb[1] + v.z * wb[2] + v.w * wb[3];
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+            sa += __shfl_xor(sa, o, 64);
+            sb += __shfl_xor(sb, o, 64);
+        }
+        if (h < H && (lane & 15) == 0) {
+            const float a = 1.f / (1.f + __expf(-(sa + ba)));
+            const float bb = 1.f / (1.f + __expf(-(sb + bb0)));
+            gate[((long)b * H + h) * T + t] = a * (bb * ga[h] - 1.f) + 2.f;
+        }
+    }
 }
 
 }  // namespace
@@ -313,10 +373,12 @@ __global__ __launch_bounds__(256) void wavlm_gate_kernel(const float* x, const f
 hipError_t launch_attention(int dtype, const AttnParams& p, hipStream_t s) {
     if (p.B <= 0 || p.T <= 0) return hipSuccess;
     dim3 grid((p.T + QT - 1) / QT, p.H, p.B), block(256);
+    const size_t dyn = p.bias_table ? (size_t)(2 * p.T - 1) * sizeof(float) : 0;  // the head's relative-position table
+    if (dyn > 24 * 1024) return hipErrorInvalidValue;  // T <= 3072 frames (61 s); beyond that the table would not fit beside K/V
     switch (dtype) {
-        case F32: hipLaunchKernelGGL(attn_f32_kernel, grid, block, 0, s, p); break;
-        case BF16: hipLaunchKernelGGL(attn_h16_kernel<bf16_tag>, grid, block, 0, s, p); break;
-        case F16: hipLaunchKernelGGL(attn_h16_kernel<f16_tag>, grid, block, 0, s, p); break;
+        case F32: hipLaunchKernelGGL(attn_f32_kernel, grid, block, dyn, s, p); break;
+        case BF16: hipLaunchKernelGGL(attn_h16_kernel<bf16_tag>, grid, block, dyn, s, p); break;
+        case F16: hipLaunchKernelGGL(attn_h16_kernel<f16_tag>, grid, block, dyn, s, p); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -324,9 +386,9 @@ hipError_t launch_attention(int dtype, const AttnParams& p, hipStream_t s) {
 
 hipError_t launch_wavlm_gate(const float* x, const float* grep_w, const float* grep_b, const float* grep_a, int B, int T,
                              int H, float* gate, hipStream_t s) {
-    const long total = (long)B * T * H;
-    hipLaunchKernelGGL(wavlm_gate_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, grep_w, grep_b, grep_a, B,
-                       T, H, gate);
+    const long rows = (long)B * T;
+    hipLaunchKernelGGL(wavlm_gate_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, grep_w, grep_b, grep_a, B, T, H,
+                       gate);
     return hipGetLastError();
 }
 
