@@ -1001,7 +1001,7 @@ int s3enc_set_tuning(const char* key, int32_t value) {
         return 0;
     }
     if (!strcmp(key, "gemm16_big")) {
-        if (value < 0 || value > 5) return fail("gemm16_big must be 0..5");
+        if (value < 0 || value > 4) return fail("gemm16_big must be 0..4");
         g_gemm16_big = value;
         return 0;
     }

@@ -25,7 +25,6 @@ namespace s3 {
 
 namespace {
 
-constexpr int BN = 256;  // tile columns
 
 template <typename T> struct Mma16;
 template <> struct Mma16<bf16_tag> {
@@ -42,14 +41,18 @@ template <> struct Mma16<f16_tag> {
 // WTM: rows per wave (tile = 2*WTM x 256); ROWB: bytes of K per row per LDS stage (128 or 64); NST: LDS stages (2: the
 // next stage lands while this one is multiplied; 3: two stages in flight, counted vmcnt); WPE: waves per SIMD the
 // register budget is capped for (2 = one workgroup per CU, 4 = two).
-template <typename T, int WTM, int ROWB, int NST, int WPE>
-__global__ __launch_bounds__(512, WPE) void gemm16_big_kernel(GemmParams p) {
-    constexpr int BM = 2 * WTM;
+// WN: waves along N (4: 8-wave workgroup, 256 columns; 2: 4-wave workgroup, 128 columns — two such workgroups per CU
+// put ONE wave of each on every SIMD, so their barriers and epilogues interleave).
+template <typename T, int WTM, int ROWB, int NST, int WPE, int WN>
+__global__ __launch_bounds__(128 * WN, WPE) void gemm16_big_kernel(GemmParams p) {
+    constexpr int NTHR = 128 * WN;  // 2 waves along M x WN along N
+    constexpr int BM = 2 * WTM, BN = 64 * WN;
     constexpr int MI = WTM / 32;  // 32-row accumulator blocks per wave
     constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE_BYTES = A_BYTES + B_BYTES;
     constexpr int SLOTS = ROWB / 16, SMASK = SLOTS - 1;  // 16-byte slots per row per stage
     constexpr int SSH = ROWB == 128 ? 1 : 2;              // swizzle: slot ^= (row >> SSH) & SMASK
-    constexpr int RPP = 512 / SLOTS;                      // rows filled by one pass of the 8 waves (64 or 128)
+    constexpr int RPP = NTHR / SLOTS;                     // rows filled by one pass of the workgroup's waves
+    constexpr int PASS_BYTES = NTHR * 16;                 // LDS bytes of one pass
     constexpr int NLA = BM / RPP, NLB = BN / RPP;         // LDS-DMA instructions per wave per stage and operand
     constexpr int NQ = SLOTS / 2;                         // 16-deep fragment steps per stage
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -57,7 +60,7 @@ __global__ __launch_bounds__(512, WPE) void gemm16_big_kernel(GemmParams p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wr = wave >> 2, wc = wave & 3;
+    const int wr = wave / WN, wc = wave % WN;
     const int half = lane >> 5;
     const int l31 = lane & 31;
 
@@ -119,8 +122,8 @@ __global__ __launch_bounds__(512, WPE) void gemm16_big_kernel(GemmParams p) {
     auto issue_piece = [&](int pc, int kt, int stage) {
         const long kb = (long)kt * ROWB;
         const unsigned sa = lds_base + stage * STAGE_BYTES;  // wave-uniform; lane l lands at + l*16
-        if (pc < NLA) glds16(a_ptr[pc] + kb, sa + pc * 8192);
-        else glds16(w_ptr[pc - NLA] + kb, sa + A_BYTES + (pc - NLA) * 8192);
+        if (pc < NLA) glds16(a_ptr[pc] + kb, sa + pc * PASS_BYTES);
+        else glds16(w_ptr[pc - NLA] + kb, sa + A_BYTES + (pc - NLA) * PASS_BYTES);
     };
     auto issue = [&](int kt, int stage) {
 #pragma unroll
@@ -132,8 +135,8 @@ __global__ __launch_bounds__(512, WPE) void gemm16_big_kernel(GemmParams p) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     };
-    auto barrier_keep_one = [&]() {
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"i"(NLA + NLB) : "memory");
+    auto barrier_keep = [&]() {
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"i"((NST - 2) * (NLA + NLB)) : "memory");
         __builtin_amdgcn_s_barrier();
     };
 
@@ -183,22 +186,20 @@ __global__ __launch_bounds__(512, WPE) void gemm16_big_kernel(GemmParams p) {
             barrier_all();
         }
     } else {
-        // ring of 3: the DMA of K-step kt+2 is issued into the stage read during kt-1 (every wave is past that
-        // step's barrier), the one of kt+1 has a whole step left to land
-        issue(0, 0);
-        if (nk > 1) {
-            issue(1, 1);
-            barrier_keep_one();
-        } else {
-            barrier_all();
-        }
-        int cur = 0, nxt = 2;
+        // ring of NST stages: K-steps kt+1 .. kt+NST-2 are in flight while kt is multiplied; the DMA of kt+NST-1 is
+        // issued (interleaved with the MFMAs) into the stage read during kt-1 — every wave is past that step's barrier.
+        // The stage barrier lets the newest NST-2 K-steps' pieces stay in flight (counted vmcnt).
+#pragma unroll
+        for (int i = 0; i < NST - 1; ++i)
+            if (i < nk) issue(i, i);
+        if (nk >= NST - 1) barrier_keep(); else barrier_all();
+        int cur = 0, nxt = NST - 1;
         for (int kt = 0; kt < nk; ++kt) {
-            const bool more = kt + 2 < nk;
-            compute(cur, more, kt + 2, nxt);
-            if (more) barrier_keep_one(); else barrier_all();
-            cur = cur == 2 ? 0 : cur + 1;
-            nxt = nxt == 2 ? 0 : nxt + 1;
+            const bool more = kt + NST - 1 < nk;
+            compute(cur, more, kt + NST - 1, nxt);
+            if (more) barrier_keep(); else barrier_all();  // tail: simply drain
+            cur = cur == NST - 1 ? 0 : cur + 1;
+            nxt = nxt == NST - 1 ? 0 : nxt + 1;
         }
     }
 
@@ -246,17 +247,17 @@ __global__ __launch_bounds__(512, WPE) void gemm16_big_kernel(GemmParams p) {
     }
 }
 
-template <typename T, int WTM, int ROWB, int NST, int WPE>
+template <typename T, int WTM, int ROWB, int NST, int WPE, int WN = 4>
 hipError_t big_go(const GemmParams& p, hipStream_t stream) {
-    constexpr int BM = 2 * WTM;
+    constexpr int BM = 2 * WTM, BN = 64 * WN, NTHR = 128 * WN;
     constexpr int lds = NST * (BM + BN) * ROWB;
-    static_assert(lds >= 8 * 8192, "epilogue staging must fit");
-    static_assert(lds * (WPE / 2) <= 160 * 1024, "workgroups per CU x LDS");
-    auto kern = gemm16_big_kernel<T, WTM, ROWB, NST, WPE>;
+    static_assert(lds >= 2 * WN * 8192, "epilogue staging must fit");
+    static_assert(lds * (WPE * 4 * 64 / NTHR) <= 160 * 1024, "workgroups per CU x LDS");
+    auto kern = gemm16_big_kernel<T, WTM, ROWB, NST, WPE, WN>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
     dim3 grid(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.batches);
-    hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, p);
+    hipLaunchKernelGGL(kern, grid, dim3(NTHR), lds, stream, p);
     return hipGetLastError();
 }
 
@@ -266,14 +267,15 @@ hipError_t big_mode(int mode, const GemmParams& p, hipStream_t stream) {
         case 1: return big_go<T, 128, 128, 2, 2>(p, stream);  // 256x256, 128 KiB, one workgroup per CU
         case 2: return big_go<T, 64, 128, 2, 2>(p, stream);   // 128x256,  96 KiB, one per CU
         case 4: return big_go<T, 64, 64, 3, 4>(p, stream);    // 128x256,  72 KiB ring of 3, two per CU
-        case 5: return big_go<T, 128, 64, 3, 2>(p, stream);   // 256x256,  96 KiB ring of 3, one per CU
+        // measured and dropped (profiles/r01_gemm16_variants.md): 256x256 with 64-byte stages in a ring of 3 / 4,
+        // 128x256 ring of 4, 4-wave 256x128 two per CU — all 5-20 % behind modes 1 / 4 on every shape of the path
     }
     return hipErrorInvalidValue;
 }
 
 }  // namespace
 
-int g_gemm16_big = 3;  // 0 off, 3 = choose by shape, 1/2/4/5 = force one configuration (see big_mode)
+int g_gemm16_big = 3;  // 0 off, 3 = choose by shape, 1 / 2 / 4 = force one configuration (see big_mode)
 
 bool gemm16_big_eligible(int dtype, const GemmParams& p) {
     if (dtype == F32 || g_gemm16_big == 0) return false;

@@ -16,6 +16,8 @@ SHAPES = {  # name: (batches, M, N, K, lda, a_bs_rows)
     "out_proj": (1, 15968, 768, 768, 768, None),
     "fc1": (1, 15968, 3072, 768, 768, None),
     "fc2": (1, 15968, 768, 3072, 3072, None),
+    "sq4k": (1, 4096, 4096, 4096, 4096, None),
+    "sq8k": (1, 8192, 8192, 8192, 8192, None),
     "L_qkv": (1, 15968, 3072, 1024, 1024, None),
     "L_out": (1, 15968, 1024, 1024, 1024, None),
     "L_fc1": (1, 15968, 4096, 1024, 1024, None),
