@@ -195,7 +195,8 @@ def main():
             # the reference computes padded frames too, so the path's work is B x F_utt(n_max)
             "path_tflops": round(world * B * flops_per_utt(cfg, n) / (ms_per_step * 1e-3) / 1e12, 2),
             "roofline": {
-                "kernel": "gemm_kernel (conv1-6 implicit GEMM + proj/qkv/out_proj/fc1/fc2)",
+                "kernel": ("gemm_kernel<float> (gemm.hip)" if args.dtype == "fp32" else "gemm16_big_kernel (gemm16.hip)")
+                          + ": conv1-6 implicit GEMM + proj/qkv/out_proj/fc1/fc2",
                 "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4), "traffic": None, "algorithmic_bytes": round(g_by / max(g_n, 1)),
                 "launches_per_step": g_n // max(args.steps, 1), "avg_launch_ms": round(g_ms / max(g_n, 1), 4),

@@ -40,8 +40,13 @@ def run(dtype, variants=None, rounds=5, shapes=None, reps=10):
             A = torch.randn(nb * rows * 512, device="cuda").to(td); a_bs = rows * 512
         W = (torch.randn(N, K, device="cuda") / K ** 0.5).to(td)
         bias = torch.randn(N, device="cuda")
-        out32 = torch.empty(nb * M * N, device="cuda") if dtype == "fp32" else None
-        out16 = torch.empty(nb * M * N, device="cuda", dtype=td) if dtype != "fp32" else None
+        # epilogue as in the encoder: conv / fc1 -> GELU, operand-type output; qkv -> plain; out_proj / fc2 -> fp32 residual
+        # added, fp32 output (the residual stream)
+        resid = name.split("_")[-1] in ("proj", "out", "fc2") or name.endswith("fc2")
+        act = 0 if (resid or "qkv" in name) else 1
+        res32 = torch.randn(nb * M * N, device="cuda") if resid else None
+        out32 = torch.empty(nb * M * N, device="cuda") if (dtype == "fp32" or resid) else None
+        out16 = torch.empty(nb * M * N, device="cuda", dtype=td) if (dtype != "fp32" and not resid) else None
         p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
         res = {v: [] for v in variants}
         ref = None
@@ -52,7 +57,7 @@ def run(dtype, variants=None, rounds=5, shapes=None, reps=10):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(reps):  # back-to-back launches: one launch alone is dominated by clock ramp / launch gaps
-                    _lib.check(lib.s3enc_op_gemm(_lib.DTYPES[dtype], p(A), lda, a_bs, p(W), p(bias), M, N, K, nb, 1, None,
+                    _lib.check(lib.s3enc_op_gemm(_lib.DTYPES[dtype], p(A), lda, a_bs, p(W), p(bias), M, N, K, nb, act, p(res32),
                                                  None, p(out32), p(out16), N, M * N, None))
                 e1.record(); torch.cuda.synchronize()
                 if r: res[v].append(e0.elapsed_time(e1) / reps)
