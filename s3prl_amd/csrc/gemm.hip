@@ -12,10 +12,11 @@
 //
 // Tiling: 128x128 output tile per 256-thread workgroup (4 wave64 as 2x2, 64x64 per wave = 2x2
 // MFMA 32x32 tiles, 64 accumulator VGPRs).  A K-stage is ROWB = 64 (default) or 128 BYTES of every row of
-// both operands, double buffered in LDS, one barrier per stage; 64-byte stages need 32 KiB of LDS so four
+// both operands, double buffered in LDS, one barrier per stage; 64-byte stages need 32 KiB of LDS so four or five
 // workgroups share a CU (VGPR-limited), which measured +5..10 % (fp32) / +20..40 % (bf16) over 128-byte stages.
-// Staging is either global -> VGPR -> ds_write (register double buffer; handles a ragged K tail) or, when K is a
-// multiple of the stage, LDS-DMA (global_load_lds_dwordx4: no staging VGPRs, no ds_write pass).
+// Staging is, when K is a multiple of the stage (default), LDS-DMA (global_load_lds_dwordx4 from inline asm: no staging
+// VGPRs — 95 instead of 119, five waves per SIMD — no ds_write pass, +4..6 % on every shape of the path), otherwise
+// global -> VGPR -> ds_write (register double buffer; handles a ragged K tail).
 // LDS rows are XOR-swizzled at 16-byte granularity (slot ^= f(row)) so every ds_read_b128 fragment read is
 // bank-conflict free (MI355X_MICROARCH §LDS); with LDS-DMA the LDS image is lane-linear, so the same
 // permutation is applied to the per-lane SOURCE address instead (cdna_hip_programming.md rule 21).
@@ -148,25 +149,40 @@ __global__ __launch_bounds__(256, ROWB == 128 ? 2 : 3) void gemm_kernel(GemmPara
     };
 
     if constexpr (GLDS) {
-        // LDS-DMA staging: each wave instruction lands 64 x 16 B = 1 KiB contiguously at a wave-uniform LDS base
+        // LDS-DMA staging: each wave instruction lands 64 x 16 B = 1 KiB contiguously at a wave-uniform LDS base.
+        // Issued from inline asm (M0 = destination written in the same statement): through the builtin hipcc treats the
+        // DMA as a pending LDS write it cannot disambiguate and drains it (vmcnt(0)) before the first fragment read of
+        // the stage being multiplied, which serialises load and compute; here completion is waited for by hand.
+        const unsigned lds0 =
+            __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem + wave * 1024);
+        auto dma = [&](const char* gsrc, unsigned dst) {
+            unsigned keep;
+            asm volatile(
+                "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                : "=&s"(keep)
+                : "v"(gsrc), "s"(dst)
+                : "memory");
+        };
         auto issue = [&](int kt, int stage) {
             const long kb = (long)kt * ROWB;
-            char* sa = smem + stage * STAGE_BYTES + wave * 1024;  // == st_off - lane*16
-            char* sw = sa + BM * ROWB;
+            const unsigned sa = lds0 + stage * STAGE_BYTES;  // == st_off - lane*16
+            const unsigned sw = sa + BM * ROWB;
 #pragma unroll
             for (int i = 0; i < NLD; ++i) {
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_ptr[i] + kb),
-                                                 (__attribute__((address_space(3))) void*)(sa + i * 4096), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_ptr[i] + kb),
-                                                 (__attribute__((address_space(3))) void*)(sw + i * 4096), 16, 0, 0);
+                dma(a_ptr[i] + kb, sa + i * 4096);
+                dma(w_ptr[i] + kb, sw + i * 4096);
             }
         };
+        auto stage_barrier = [&]() {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        };
         issue(0, 0);
-        __syncthreads();
+        stage_barrier();
         for (int kt = 0; kt < nk; ++kt) {
             if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
             compute(kt & 1);
-            __syncthreads();  // drains this wave's DMA (vmcnt) and orders everyone's reads before the next overwrite
+            stage_barrier();  // my DMA landed + my fragment reads done, then everybody's
         }
     } else {
         uint4 ga[NLD], gw[NLD];
@@ -245,7 +261,7 @@ hipError_t gemm_variant(const GemmParams& p, dim3 grid, hipStream_t stream, bool
 
 }  // namespace
 
-int g_gemm_variant = 1;
+int g_gemm_variant = 3;  // 64-byte stages + LDS-DMA (falls back to register staging for a ragged K)
 
 hipError_t launch_gemm(int dtype, const GemmParams& p0, hipStream_t stream) {
     GemmParams p = p0;

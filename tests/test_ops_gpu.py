@@ -56,7 +56,7 @@ def test_gemm_variants(dtype, case, variant):
     try:
         test_gemm(dtype, case)
     finally:
-        _lib.check(lib.s3enc_set_tuning(b"gemm_variant", 1))
+        _lib.check(lib.s3enc_set_tuning(b"gemm_variant", 3))
 
 
 @pytest.mark.parametrize("mode", [1, 2, 4, 0])
