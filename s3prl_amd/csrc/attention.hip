@@ -32,8 +32,10 @@ struct BiasCtx {
 };
 
 __global__ __launch_bounds__(256) void attn_f32_kernel(AttnParams p) {
-    __shared__ __attribute__((aligned(16))) float Ks[KT * KS32];
-    __shared__ __attribute__((aligned(16))) float Vs[KT * KS32];
+    // K and V tiles double-buffered in LDS; the next tile's global loads are in flight (registers) while the current
+    // tile is multiplied: one barrier per 32 keys
+    __shared__ __attribute__((aligned(16))) float Ks[2 * KT * KS32];
+    __shared__ __attribute__((aligned(16))) float Vs[2 * KT * KS32];
     const int b = blockIdx.z, head = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
@@ -74,24 +76,33 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnParams p) {
 
     const int valid = p.valid[b];
     const int ntiles = (valid + KT - 1) / KT;
+    f32x4 kreg[2], vreg[2];  // native vectors (HIP float4 arrays held across the loop end up in scratch)
+    const int srow = tid >> 4, sc4 = tid & 15;  // staging: rows srow and srow+16, float4 column sc4
+#define A32_LOAD(kt_)                                                                        \
+    _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                       \
+        int kr_ = (kt_) * KT + srow + 16 * i_;                                               \
+        kr_ = kr_ < p.T ? kr_ : p.T - 1;                                                     \
+        const float* src_ = base + (long)kr_ * ld + sc4 * 4;                                 \
+        kreg[i_] = *(const f32x4*)(src_ + D);                                                \
+        vreg[i_] = *(const f32x4*)(src_ + 2 * D);                                            \
+    }
+#define A32_STORE(buf_)                                                                      \
+    _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                       \
+        *(f32x4*)(Ks + (buf_) * KT * KS32 + (srow + 16 * i_) * KS32 + sc4 * 4) = kreg[i_];   \
+        *(f32x4*)(Vs + (buf_) * KT * KS32 + (srow + 16 * i_) * KS32 + sc4 * 4) = vreg[i_];   \
+    }
+    A32_LOAD(0)
+    A32_STORE(0)
+    __syncthreads();
     for (int kt = 0; kt < ntiles; ++kt) {
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int idx = tid + 256 * i;
-            const int row = idx >> 4, c4 = idx & 15;
-            int kr = kt * KT + row;
-            kr = kr < p.T ? kr : p.T - 1;
-            const float* src = base + (long)kr * ld + c4 * 4;
-            *(float4*)(Ks + row * KS32 + c4 * 4) = *(const float4*)(src + D);
-            *(float4*)(Vs + row * KS32 + c4 * 4) = *(const float4*)(src + 2 * D);
-        }
-        __syncthreads();
+        if (kt + 1 < ntiles) { A32_LOAD(kt + 1) }
+        const float* Kb = Ks + (kt & 1) * KT * KS32;
+        const float* Vb = Vs + (kt & 1) * KT * KS32;
 
         f32x16 s;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
-        const float* kp = Ks + l31 * KS32 + half * 32;
+        const float* kp = Kb + l31 * KS32 + half * 32;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const float4 kf = *(const float4*)(kp + 4 * i);
@@ -100,39 +111,53 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnParams p) {
             s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[4 * i + 2], s, 0, 0, 0);
             s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[4 * i + 3], s, 0, 0, 0);
         }
-        float mx = -INFINITY;
+        // bias / mask passes only where they apply; the running max is only raised (and O, l rescaled) when some
+        // query's tile max exceeds it by more than 8 — softmax is invariant to the reference point (exact in real
+        // arithmetic, rounding-level in fp32) and the 32 O registers are then almost never rescaled
+        if (btab) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = kt * KT + crow(r, half);
-            float v = s[r];
-            if (btab && key < p.T) v += gate * btab[key - q_c + p.T - 1];
-            v = key < valid ? v : -INFINITY;
-            s[r] = v;
-            mx = fmaxf(mx, v);
+            for (int r = 0; r < 16; ++r) {
+                const int key = kt * KT + crow(r, half);
+                if (key < p.T) s[r] += gate * btab[key - q_c + p.T - 1];
+            }
         }
+        if (kt * KT + KT > valid) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = kt * KT + crow(r, half) < valid ? s[r] : -INFINITY;
+        }
+        float mx = s[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __expf(m_run - m_new);
+        if (__any(mx > m_run + 8.f)) {
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __expf(m_run - m_new);
+            l_run *= alpha;
+            m_run = m_new;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                o0[r] *= alpha;
+                o1[r] *= alpha;
+            }
+        }
         float ps = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            s[r] = __expf(s[r] - m_new);
+            s[r] = __expf(s[r] - m_run);
             ps += s[r];
         }
-        l_run = l_run * alpha + ps;
-        m_run = m_new;
+        l_run += ps;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            o0[r] *= alpha;
-            o1[r] *= alpha;
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float* vp = Vs + crow(r, half) * KS32 + l31;
+            const float* vp = Vb + crow(r, half) * KS32 + l31;
             o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[0], s[r], o0, 0, 0, 0);
             o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[32], s[r], o1, 0, 0, 0);
         }
+        if (kt + 1 < ntiles) { A32_STORE((kt + 1) & 1) }
+        __syncthreads();
     }
+#undef A32_LOAD
+#undef A32_STORE
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.f / l_tot;
     if (q_g < p.T) {
