@@ -6,6 +6,7 @@ picks up the MI355X path without edits to the reference tree."""
 from .upstream.hubert.hubconf import *  # noqa: F401,F403
 from .upstream.wav2vec2.hubconf import *  # noqa: F401,F403
 from .upstream.wavlm.hubconf import *  # noqa: F401,F403
+from .upstream.unispeech_sat.hubconf import *  # noqa: F401,F403
 from .upstream.baseline.hubconf import *  # noqa: F401,F403
 
 

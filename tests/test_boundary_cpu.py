@@ -43,9 +43,11 @@ def test_hub_entries_follow_the_reference_naming():
     import s3prl_amd.hub as hub
 
     names = hub.options()
-    for fam in ("hubert", "wav2vec2", "wavlm"):
+    for fam in ("hubert", "wav2vec2", "wavlm", "unispeech_sat"):
         assert fam in names and f"{fam}_local" in names and f"{fam}_custom" in names
     assert all(not n.endswith("_local") for n in hub.options(only_registered_ckpt=True))
+    for n in ("fbank", "fbank_no_cmvn", "baseline", "baseline_local"):
+        assert n in names
     with pytest.raises(RuntimeError, match="no network"):
         hub.hubert()
 
