@@ -156,7 +156,10 @@ __global__ __launch_bounds__(128 * WN, WPE) void gemm16_big_kernel(GemmParams p)
     // multiply stage `stage`; when `pf`, also issue the DMA pieces of K-step kt_pf into stage_pf, spread over the
     // NQ fragment steps (right after each step's ds_reads): an LDS-DMA instruction costs 60-180 issue cycles
     // (MI355X_MICROARCH.md), so 8 of them issued up front would idle the matrix pipe for ~1/3 of a K-step
-    constexpr int PPQ = (NL + NQ - 1) / NQ;
+    // 2-stage pipeline: the pieces must land before THIS step's barrier, so they are issued in its first half;
+    // rings of 3+ wait for an older K-step and spread them over the whole step
+    constexpr int NQI = (NST == 2 && NQ >= 4) ? NQ / 2 : NQ;
+    constexpr int PPQ = (NL + NQI - 1) / NQI;
     auto compute = [&](int stage, bool pf, int kt_pf, int stage_pf) {
         const char* st = smem + stage * STAGE_BYTES;
 #pragma unroll
