@@ -996,7 +996,7 @@ int s3enc_debug_tap(s3enc_handle h, const char* name, float* host_out, int64_t m
 int s3enc_set_tuning(const char* key, int32_t value) {
     if (!key) return fail("s3enc_set_tuning: null key");
     if (!strcmp(key, "gemm_variant")) {
-        if (value < 0 || value > 15) return fail("gemm_variant must be 0..15");
+        if (value < 0 || value > 63) return fail("gemm_variant must be 0..63");
         g_gemm_variant = value;
         return 0;
     }

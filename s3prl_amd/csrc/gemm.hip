@@ -53,8 +53,8 @@ template <> struct Mma<f16_tag> {
     }
 };
 
-template <typename T, int ROWB, bool GLDS>
-__global__ __launch_bounds__(256, ROWB == 128 ? 2 : 3) void gemm_kernel(GemmParams p) {
+template <typename T, int ROWB, bool GLDS, bool VEC>
+__global__ __launch_bounds__(256, ROWB == 128 ? 2 : (GLDS ? 5 : 3)) void gemm_kernel(GemmParams p) {
     typedef typename Cvt<T>::store_t store_t;
     constexpr int EB = sizeof(store_t);
     constexpr int STAGE_BYTES = (BM + BN) * ROWB;
@@ -218,6 +218,51 @@ __global__ __launch_bounds__(256, ROWB == 128 ? 2 : 3) void gemm_kernel(GemmPara
     // ---- epilogue: acc[i][j][r] is (row = wr*64+i*32 + (r&3)+8*(r>>2)+4*half, col = wc*64+j*32+l31) ----
     const int limit = p.row_limit ? p.row_limit[b] : p.M;
     const long ob = (long)b * p.o_bs;
+    if constexpr (VEC) {
+        // vector epilogue (launcher-checked: N, ldo, o_bs multiples of 4, 16-byte aligned pointers): the accumulators go
+        // through a wave-private LDS transpose (32 x 64 fp32 per step; the stage buffers are free after the last
+        // barrier) so that bias / GELU / residual run on row-contiguous float4s and every global access is a 16-byte
+        // (fp32) or 8-byte (16-bit) vector — 16 store instructions per wave instead of 64
+        float* stg = (float*)(smem + wave * 8192);
+        const int c4 = (lane & 15) * 4;
+        const int n = n0 + wc * 64 + c4;
+        const bool n_ok = n < p.N;
+        float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.bias && n_ok) bias4 = *(const float4*)(p.bias + n);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + 4 * half) * 64 + j * 32 + l31] = acc[i][j][r];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int row = t * 4 + (lane >> 4);
+                float4 v = *(const float4*)(stg + row * 64 + c4);
+                const int m = m0 + wr * 64 + i * 32 + row;
+                if (m < p.M && n_ok) {
+                    v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+                    if (p.act) {
+                        v.x = gelu_mode<T>(v.x); v.y = gelu_mode<T>(v.y); v.z = gelu_mode<T>(v.z); v.w = gelu_mode<T>(v.w);
+                    }
+                    const long o = ob + (long)m * p.ldo + n;
+                    if (p.residual) {
+                        const float4 rs = *(const float4*)(p.residual + o);
+                        v.x += rs.x; v.y += rs.y; v.z += rs.z; v.w += rs.w;
+                    }
+                    if (m >= limit) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (p.out32) *(float4*)(p.out32 + o) = v;
+                    if (p.out16) {
+                        ushort4 h;
+                        h.x = Cvt<T>::to(v.x); h.y = Cvt<T>::to(v.y); h.z = Cvt<T>::to(v.z); h.w = Cvt<T>::to(v.w);
+                        *(ushort4*)((store_t*)p.out16 + o) = h;
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    } else {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int n = n0 + wc * 64 + j * 32 + l31;
@@ -239,24 +284,32 @@ __global__ __launch_bounds__(256, ROWB == 128 ? 2 : 3) void gemm_kernel(GemmPara
             }
         }
     }
+    }
 }
 
-template <typename T, int ROWB, bool GLDS>
+template <typename T, int ROWB, bool GLDS, bool VEC>
 hipError_t gemm_go(const GemmParams& p, dim3 grid, hipStream_t stream) {
     constexpr int lds = 2 * (BM + BN) * ROWB;
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<T, ROWB, GLDS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    static_assert(lds >= 4 * 8192, "epilogue staging must fit");
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<T, ROWB, GLDS, VEC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((gemm_kernel<T, ROWB, GLDS>), grid, dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((gemm_kernel<T, ROWB, GLDS, VEC>), grid, dim3(256), lds, stream, p);
     return hipGetLastError();
 }
 
-// variant bits: 1 = 64-byte K stages (else 128), 2 = LDS-DMA staging, 4 = no XCD-aware tile order (A/B only)
-template <typename T>
-hipError_t gemm_variant(const GemmParams& p, dim3 grid, hipStream_t stream, bool k_aligned64, bool k_aligned128) {
+// variant bits: 1 = 64-byte K stages (else 128), 2 = LDS-DMA staging, 4 = no XCD-aware tile order (A/B only),
+//               16 = vector epilogue (set by the launcher when the alignment allows), 32 = force the scalar epilogue
+template <typename T, bool VEC>
+hipError_t gemm_variant2(const GemmParams& p, dim3 grid, hipStream_t stream, bool k_aligned64, bool k_aligned128) {
     const bool small = p.variant & 1;
     const bool glds = (p.variant & 2) && (small ? k_aligned64 : k_aligned128);  // DMA cannot zero-fill a ragged K tail
-    if (small) return glds ? gemm_go<T, 64, true>(p, grid, stream) : gemm_go<T, 64, false>(p, grid, stream);
-    return glds ? gemm_go<T, 128, true>(p, grid, stream) : gemm_go<T, 128, false>(p, grid, stream);
+    if (small) return glds ? gemm_go<T, 64, true, VEC>(p, grid, stream) : gemm_go<T, 64, false, VEC>(p, grid, stream);
+    return glds ? gemm_go<T, 128, true, VEC>(p, grid, stream) : gemm_go<T, 128, false, VEC>(p, grid, stream);
+}
+template <typename T>
+hipError_t gemm_variant(const GemmParams& p, dim3 grid, hipStream_t stream, bool k_aligned64, bool k_aligned128) {
+    return (p.variant & 16) ? gemm_variant2<T, true>(p, grid, stream, k_aligned64, k_aligned128)
+                            : gemm_variant2<T, false>(p, grid, stream, k_aligned64, k_aligned128);
 }
 
 }  // namespace
@@ -268,7 +321,12 @@ hipError_t launch_gemm(int dtype, const GemmParams& p0, hipStream_t stream) {
     if (p.variant < 0) p.variant = g_gemm_variant;
     if (p.M <= 0 || p.N <= 0 || p.batches <= 0) return hipSuccess;
     if (gemm16_big_eligible(dtype, p)) return launch_gemm16_big(dtype, p, stream);
-    p.variant &= 7;
+    p.variant &= 7 | 32;  // bit 5 (tuning): force the scalar epilogue
+    {   // vector epilogue when every output / residual / bias access can be a 16-byte (8-byte for 16-bit) vector
+        const uintptr_t al = (uintptr_t)p.out32 | (uintptr_t)p.residual | (uintptr_t)p.bias;
+        const bool ok = !(p.N & 3) && !(p.ldo & 3) && !(p.o_bs & 3) && !(al & 15) && !(((uintptr_t)p.out16) & 7);
+        if (ok && !(p.variant & 32)) p.variant |= 16;
+    }
     const int eb = dtype == F32 ? 4 : 2;
     // 16-byte vector loads: row starts and K must be 16-byte granular
     if (((p.lda * eb) & 15) || ((p.a_bs * eb) & 15) || (((long)p.K * eb) & 15) || (((uintptr_t)p.A) & 15) ||

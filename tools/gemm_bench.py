@@ -16,6 +16,9 @@ SHAPES = {  # name: (batches, M, N, K, lda, a_bs_rows)
     "out_proj": (1, 15968, 768, 768, 768, None),
     "fc1": (1, 15968, 3072, 768, 768, None),
     "fc2": (1, 15968, 768, 3072, 3072, None),
+    "ep_fc2": (1, 15968, 768, 64, 64, None),    # K = 64: prologue + epilogue only (residual, fp32 out)
+    "ep_fc1": (1, 15968, 3072, 64, 64, None),   # K = 64: prologue + epilogue only (GELU, 16-bit out)
+    "ep_qkv": (1, 15968, 2304, 64, 64, None),   # K = 64: prologue + epilogue only (plain, 16-bit out)
     "sq4k": (1, 4096, 4096, 4096, 4096, None),
     "sq8k": (1, 8192, 8192, 8192, 8192, None),
     "L_qkv": (1, 15968, 3072, 1024, 1024, None),
