@@ -19,6 +19,8 @@
 //     mode (gemm.hip) keeps erff.
 // Requirements (checked by the launcher, which otherwise falls back to gemm.hip): K a multiple of 64, N / ldo /
 // o_bs multiples of 4, 16-byte aligned operands and outputs.
+#include <type_traits>
+
 #include "kernels.h"
 
 namespace s3 {
@@ -207,6 +209,8 @@ __global__ __launch_bounds__(128 * WN, WPE) void gemm16_big_kernel(GemmParams p)
     }
 
     // ---- epilogue through a wave-private LDS transpose: 32 x 64 fp32 per step ----
+    // Specialised at compile time on (GELU, residual, fp32 out, 16-bit out) for the four combinations the encoder uses
+    // — the generic form tests five uniform flags per 4-row pass (168 branches per tile) — with a generic fallback.
     typedef typename Cvt<T>::store_t store_t;
     float* stg = (float*)(smem + wave * 8192);
     const int limit = p.row_limit ? p.row_limit[b] : p.M;
@@ -216,38 +220,52 @@ __global__ __launch_bounds__(128 * WN, WPE) void gemm16_big_kernel(GemmParams p)
     const bool n_ok = n < p.N;  // N % 4 == 0: a float4 is inside or outside as a whole
     float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.bias && n_ok) bias4 = *(const float4*)(p.bias + n);
+    auto epilogue = [&](auto spec, auto act_c, auto res_c, auto o32_c, auto o16_c) {
+        constexpr bool SPEC = decltype(spec)::value;
+        const bool act = SPEC ? decltype(act_c)::value : (p.act != 0);
+        const bool res = SPEC ? decltype(res_c)::value : (p.residual != nullptr);
+        const bool o32 = SPEC ? decltype(o32_c)::value : (p.out32 != nullptr);
+        const bool o16 = SPEC ? decltype(o16_c)::value : (p.out16 != nullptr);
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
+        for (int i = 0; i < MI; ++i) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                stg[((r & 3) + 8 * (r >> 2) + 4 * half) * 64 + j * 32 + l31] = acc[i][j][r];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                for (int r = 0; r < 16; ++r)
+                    stg[((r & 3) + 8 * (r >> 2) + 4 * half) * 64 + j * 32 + l31] = acc[i][j][r];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const int row = t * 4 + (lane >> 4);
-            float4 v = *(const float4*)(stg + row * 64 + c4);
-            const int m = m0 + wr * WTM + i * 32 + row;
-            if (m < p.M && n_ok) {
-                v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
-                if (p.act) {
-                    v.x = gelu_fast(v.x); v.y = gelu_fast(v.y); v.z = gelu_fast(v.z); v.w = gelu_fast(v.w);
-                }
-                const long o = ob + (long)m * p.ldo + n;
-                if (p.residual) {
-                    const float4 rs = *(const float4*)(p.residual + o);
-                    v.x += rs.x; v.y += rs.y; v.z += rs.z; v.w += rs.w;
-                }
-                if (m >= limit) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (p.out32) *(float4*)(p.out32 + o) = v;
-                if (p.out16) {
-                    *(uint2*)((store_t*)p.out16 + o) = make_uint2(Cvt<T>::pack2(v.x, v.y), Cvt<T>::pack2(v.z, v.w));
+            for (int t = 0; t < 8; ++t) {
+                const int row = t * 4 + (lane >> 4);
+                float4 v = *(const float4*)(stg + row * 64 + c4);
+                const int m = m0 + wr * WTM + i * 32 + row;
+                if (m < p.M && n_ok) {
+                    v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+                    if (act) {
+                        v.x = gelu_fast(v.x); v.y = gelu_fast(v.y); v.z = gelu_fast(v.z); v.w = gelu_fast(v.w);
+                    }
+                    const long o = ob + (long)m * p.ldo + n;
+                    if (res) {
+                        const float4 rs = *(const float4*)(p.residual + o);
+                        v.x += rs.x; v.y += rs.y; v.z += rs.z; v.w += rs.w;
+                    }
+                    if (!SPEC && m >= limit) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (o32) *(float4*)(p.out32 + o) = v;
+                    if (o16) *(uint2*)((store_t*)p.out16 + o) = make_uint2(Cvt<T>::pack2(v.x, v.y), Cvt<T>::pack2(v.z, v.w));
                 }
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
+    };
+    using TT = std::true_type;
+    using FF = std::false_type;
+    const bool a = p.act != 0, r = p.residual != nullptr, w32 = p.out32 != nullptr, w16 = p.out16 != nullptr;
+    if (p.row_limit) epilogue(FF{}, FF{}, FF{}, FF{}, FF{});                         // generic (proj: padded-frame zeroing)
+    else if (a && !r && !w32 && w16) epilogue(TT{}, TT{}, FF{}, FF{}, TT{});          // conv1-5, fc1
+    else if (!a && !r && !w32 && w16) epilogue(TT{}, FF{}, FF{}, FF{}, TT{});         // q|k|v
+    else if (!a && r && w32 && !w16) epilogue(TT{}, FF{}, TT{}, TT{}, FF{});          // out_proj, fc2
+    else if (a && !r && w32 && !w16) epilogue(TT{}, TT{}, FF{}, TT{}, FF{});          // last conv (feeds the fp32 LayerNorm)
+    else epilogue(FF{}, FF{}, FF{}, FF{}, FF{});
 }
 
 template <typename T, int WTM, int ROWB, int NST, int WPE, int WN = 4>
