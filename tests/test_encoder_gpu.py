@@ -254,3 +254,23 @@ def test_full_size_mixed_lengths_valid_frames_match_oracle():
         got = full[l][[0, short]].cpu().numpy()
         assert O.rel_err(got, ref[l].numpy()) < FP32_TOL, f"layer {l}"
     enc.close()
+
+
+@pytest.mark.parametrize("name", ["tiny_hubert", "tiny_wavlm_large"])
+def test_long_single_utterance_and_one_frame_neighbour(name):
+    """Edge shapes: B = 1 with 40 s of audio (T = 1999: the WavLM relative-position table spans 3997 entries, attention
+    walks 63 key tiles) and a batch that pairs it with a 400-sample utterance (1 valid frame, everything else masked)."""
+    import torch
+    from s3prl_amd.synth import named_config, synth_wavs, synth_weights
+
+    cfg = named_config(name)
+    weights = synth_weights(cfg, 2)
+    enc = _encoder(cfg, weights)
+    for lengths in ([640000], [640000, 400]):
+        wavs = synth_wavs(lengths, seed=9)
+        hs = _run(enc, wavs)
+        assert hs.shape[2] == 1999 and np.isfinite(hs).all()
+        ref = O.forward(cfg, weights, wavs, dtype=np.float64)
+        for l, r in enumerate(ref):
+            assert O.rel_err(hs[l], r) < 5e-5, f"{lengths} layer {l}: {O.rel_err(hs[l], r):.2e}"
+    enc.close()
