@@ -166,7 +166,7 @@ struct s3enc_encoder {
     std::vector<hipEvent_t> layer_events;  // caller-owned, recorded when hidden_states[l] is final
 
     // profiling
-    bool prof = false;
+    int prof = 0;  // 0 off, 1 every kernel, 2 only the GEMM launches (the dominant kernel: cheap enough for a timed region)
     std::vector<std::string> kinds;
     std::vector<double> kflops, kbytes;
     std::vector<long> klaunches;
@@ -209,6 +209,7 @@ struct Prof {
     int idx = -1;
     Prof(s3enc_encoder* enc, hipStream_t s, const char* kind, double flops, double bytes) : e(enc), st(s) {
         if (!e || !e->prof) return;
+        if (e->prof == 2 && strncmp(kind, "gemm", 4) != 0) return;
         const int k = e->kind_id(kind);
         e->kflops[k] += flops;
         e->kbytes[k] += bytes;
@@ -933,7 +934,7 @@ int s3enc_set_layer_events(s3enc_handle h, void* const* events, int32_t n) {
 
 int s3enc_profile_enable(s3enc_handle h, int32_t on) {
     if (!h) return fail("null handle");
-    h->prof = on != 0;
+    h->prof = on == 2 ? 2 : (on != 0);
     return 0;
 }
 int s3enc_profile_reset(s3enc_handle h) {

@@ -127,7 +127,8 @@ class HipEncoder:
         return self._events
 
     # ---- measurement / test hooks ----
-    def profile_enable(self, on: bool = True):
+    def profile_enable(self, on=True):
+        """True / 1: HIP events around every kernel; 2: only around the GEMM launches; False / 0: off."""
         _lib.check(self._lib.s3enc_profile_enable(self._h, int(on)))
 
     def profile_reset(self):
