@@ -139,7 +139,10 @@ __global__ __launch_bounds__(256) void gn_final_kernel(const double* partial, in
 // ---- conv0 -------------------------------------------------------------------------------------------------
 constexpr int C0_FT = 64;  // frames per block
 
-template <typename T, int NG, int K0>
+// CS = waves that share one frame, each owning a contiguous C / CS slice of the channels (GroupNorm mode only: no
+// reduction across channels).  CS = 2 for C = 512 halves the per-lane weight registers (149 -> 81 VGPRs, 3 -> 5-6 waves
+// per SIMD), which is what lets the GELU arithmetic of one wave overlap the 1 KiB row stores of another.
+template <typename T, int NG, int K0, int CS = 1>
 __global__ __launch_bounds__(256) void conv0_kernel(Conv0Params p) {
     typedef typename Cvt<T>::store_t store_t;
     __shared__ float xs[(C0_FT - 1) * 8 + STAT_K0_MAX];  // stride <= 8 supported
@@ -152,14 +155,15 @@ __global__ __launch_bounds__(256) void conv0_kernel(Conv0Params p) {
     const int nwin = (C0_FT - 1) * p.s0 + K0;
     for (int i = threadIdx.x; i < nwin; i += 256) xs[i] = load_wav(x, len, t0 * p.s0 + i, mean, rstd);
 
-    // per-lane constants: channels 4*(lane+64g) .. +3
+    // per-lane constants: channels coff + 4*(lane+64g) .. +3
+    const int coff = (wave % CS) * (NG * 256);
     float w[NG][4][K0];
     float a0[NG][4], a1[NG][4];  // GN: scale, shift;  LN: gamma, beta
     float cb[NG][4];
     bool act[NG];
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-        const int c0 = 4 * (lane + 64 * g);
+        const int c0 = coff + 4 * (lane + 64 * g);
         act[g] = c0 < p.C;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -180,7 +184,7 @@ __global__ __launch_bounds__(256) void conv0_kernel(Conv0Params p) {
     __syncthreads();
 
     const float invC = 1.f / (float)p.C;
-    for (int f = wave; f < C0_FT; f += 4) {
+    for (int f = wave / CS; f < C0_FT; f += 4 / CS) {
         const long t = t0 + f;
         if (t >= p.L0) break;
         float xv[K0];
@@ -230,7 +234,7 @@ __global__ __launch_bounds__(256) void conv0_kernel(Conv0Params p) {
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             if (!act[g]) continue;
-            const int c0 = 4 * (lane + 64 * g);
+            const int c0 = coff + 4 * (lane + 64 * g);
             if constexpr (sizeof(store_t) == 4) {
                 *(float4*)(o + c0) = make_float4(v[g][0], v[g][1], v[g][2], v[g][3]);
             } else {
@@ -251,6 +255,8 @@ hipError_t conv0_dispatch(const Conv0Params& p, hipStream_t s) {
     const int ng = (p.C + 255) / 256;
     if (ng <= 1)
         hipLaunchKernelGGL((conv0_kernel<T, 1, 10>), grid, dim3(256), 0, s, p);
+    else if (ng == 2 && p.gn)  // GroupNorm extractor (base models): two waves per frame, 256 channels each
+        hipLaunchKernelGGL((conv0_kernel<T, 1, 10, 2>), grid, dim3(256), 0, s, p);
     else if (ng == 2)
         hipLaunchKernelGGL((conv0_kernel<T, 2, 10>), grid, dim3(256), 0, s, p);
     else
