@@ -6,17 +6,25 @@
 // bounded by what feeds the matrix pipe, not by the pipe: 64 FLOP per byte staged from L2 and 1 KiB of LDS reads per
 // MFMA.  Here a 512-thread workgroup owns a (2*WTM) x 256 tile, 8 wave64 as 2(M) x 4(N), each wave a WTM x 64
 // sub-tile (WTM = 128: 8 accumulator tiles of 32x32 = 128 VGPRs; 128 FLOP per staged byte, 0.75 KiB LDS per MFMA).
-//   * staging: LDS-DMA only (global_load_lds_dwordx4, 1 KiB per wave instruction, whole 128-byte lines of a row
-//     per 8 lanes), two stages of 64 K-values, the next stage in flight while the current one is multiplied;
-//     LDS rows are XOR-swizzled through the per-lane SOURCE address (the DMA image is lane-linear) so every
-//     ds_read_b128 fragment read is bank-conflict free — same layout as gemm.hip's 128-byte stages.
+//   * staging: LDS-DMA only (global_load_lds_dwordx4, 1 KiB per wave instruction, whole lines of a row per 8 / 4
+//     lanes), issued from INLINE ASM with hand-counted vmcnt: through the builtin hipcc drains the DMA (vmcnt(0))
+//     before the first fragment read of every K-step, which serialises load and compute.  Two configurations ship:
+//       mode 1  256x256 tile, 2 stages of 64 k, one workgroup per CU (128 FLOP per staged byte) — K >= 1536;
+//       mode 4  128x256 tile, ring of 3 stages of 32 k with two K-steps in flight, two workgroups per CU that hide
+//               each other's barriers and epilogues — short K (768 / 1024), where prologue + epilogue are 25-45 % of
+//               a tile's time.
+//     The DMA pieces are interleaved with the MFMA steps (an LDS-DMA instruction costs 60-180 issue cycles).  LDS rows
+//     are XOR-swizzled through the per-lane SOURCE address (the DMA image is lane-linear) so every ds_read_b128
+//     fragment read is bank-conflict free — same layout as gemm.hip.
 //   * epilogue: accumulators go through a wave-private LDS transpose (32 x 64 fp32 per step) so that bias, GELU,
 //     residual and the padded-frame zeroing run on row-contiguous float4s and every global access is a full
-//     16-byte (fp32) / 8-byte (16-bit) vector: 8 store instructions per 32x64 block instead of 32.
+//     16-byte (fp32) / 8-byte (16-bit) vector; specialised at compile time on the four flag combinations of the path;
+//     v_cvt_pk_bf16_f32 / v_cvt_f16_f32 for the 16-bit stores.
 //   * GELU in the 16-bit modes uses a 1.5e-7-accurate erf (Abramowitz-Stegun 7.1.26: one v_exp + one v_rcp + a
-//     degree-5 Horner) instead of libm's erff: at K = 768 the erff epilogue costs about as many VALU cycles as the
-//     whole K loop costs MFMA cycles.  The error is 3 orders below the operand rounding of these modes; the fp32
-//     mode (gemm.hip) keeps erff.
+//     degree-5 Horner, 19 VALU) instead of libm's erff (38 VALU with a divergent branch): at K = 768 the erff
+//     epilogue costs about as many VALU cycles as the whole K loop costs MFMA cycles.  The error is 3 orders below
+//     the operand rounding of these modes; the fp32 mode (gemm.hip) keeps erff.
+// Measured: profiles/r01_gemm16_variants.md (550-1100 TF on the shapes of the path, 1148 TF at 8192^3).
 // Requirements (checked by the launcher, which otherwise falls back to gemm.hip): K a multiple of 64, N / ldo /
 // o_bs multiples of 4, 16-byte aligned operands and outputs.
 #include <type_traits>
