@@ -20,7 +20,7 @@ template <int DG>
 __global__ __launch_bounds__(256) void posconv_kernel(PosConvParams p) {
     constexpr int NT = DG / 16;       // 16-wide output-channel tiles
     constexpr int NCC = DG / 16;      // 16-deep input-channel chunks
-    constexpr int RS = DG + 4;        // LDS row stride of the x window (floats)
+    constexpr int RS = DG + 8;        // LDS row stride of the x window (floats): +8 makes the float4 A reads conflict-free (+4: 2-way)
     constexpr int WSZ = DG * DG;      // floats per tap
     constexpr int NWV = (WSZ / 4 + 255) / 256;  // float4 per thread per tap
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void posconv_kernel(PosConvParams p) {
 template <int DG>
 hipError_t pc_launch(const PosConvParams& p, hipStream_t s) {
     const int rows = PC_TM + p.K - 1;
-    const size_t lds = (size_t)(((rows * (DG + 4) + 3) & ~3) + 2 * DG * DG) * sizeof(float);
+    const size_t lds = (size_t)(((rows * (DG + 8) + 3) & ~3) + 2 * DG * DG) * sizeof(float);
     hipError_t e = hipFuncSetAttribute((const void*)posconv_kernel<DG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     dim3 grid((p.T + PC_TM - 1) / PC_TM, p.G, p.B);
