@@ -274,3 +274,25 @@ def test_long_single_utterance_and_one_frame_neighbour(name):
         for l, r in enumerate(ref):
             assert O.rel_err(hs[l], r) < 5e-5, f"{lengths} layer {l}: {O.rel_err(hs[l], r):.2e}"
     enc.close()
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
+def test_race_screen_repeated_runs_are_bit_identical(dtype):
+    """The GEMM kernels overlap LDS-DMA (issued from inline asm, hand-counted vmcnt) with the MFMA loop; a missing wait
+    or barrier would show as run-to-run differences.  HuBERT-base shapes (every GEMM mode of the path: 128x128 fp32,
+    256x256 2-stage and 128x256 ring-of-3 16-bit), 8 runs, all bit-identical."""
+    import torch
+    from s3prl_amd.synth import named_config, synth_weights
+
+    cfg = named_config("hubert_base")
+    enc = _encoder(cfg, synth_weights(cfg, 0), dtype=dtype)
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    wavs = [torch.randn(n, device="cuda", generator=gen) for n in (64000, 64000, 51234, 16000, 64000, 33333)]
+    first = enc.forward(wavs).clone()
+    torch.cuda.synchronize()
+    assert torch.isfinite(first).all()
+    for _ in range(7):
+        again = enc.forward(wavs)
+        torch.cuda.synchronize()
+        assert torch.equal(again, first)
+    enc.close()
