@@ -79,6 +79,8 @@ def main():
                     help="mixed-length batch (BASELINE configs[4] recipe): utterance 0 has --secs, the rest "
                          "randint(1 s, --secs), seed 1234; frames are counted per utterance (sum of T_i)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tune", action="append", default=[], metavar="KEY=INT",
+                    help="s3enc_set_tuning knob for A/B runs (e.g. gemm16_big=4); results are unchanged")
     ap.add_argument("--no-profile", action="store_true", help="no per-kernel HIP events in the timed region (A/B of their cost)")
     ap.add_argument("--cpu-sample", type=int, default=32, help="utterances of the workload timed on the CPU oracle")
     ap.add_argument("--parity-sample", type=int, default=2, help="utterances checked against the numpy oracle")
@@ -110,6 +112,12 @@ def main():
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
     dev = torch.device("cuda", torch.cuda.current_device())
 
+    if args.tune:
+        from s3prl_amd import _lib
+
+        for kv in args.tune:
+            k, v = kv.split("=")
+            _lib.check(_lib.load().s3enc_set_tuning(k.encode(), int(v)), "s3enc_set_tuning")
     cfg = named_config(args.model)
     weights = synth_weights(cfg, 0)  # random-init weights of the named architecture (no checkpoints offline)
     enc = HipEncoder(cfg, weights, dtype=args.dtype, device=dev.index)

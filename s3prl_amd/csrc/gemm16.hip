@@ -9,9 +9,9 @@
 //   * staging: LDS-DMA only (global_load_lds_dwordx4, 1 KiB per wave instruction, whole lines of a row per 8 / 4
 //     lanes), issued from INLINE ASM with hand-counted vmcnt: through the builtin hipcc drains the DMA (vmcnt(0))
 //     before the first fragment read of every K-step, which serialises load and compute.  Two configurations ship:
-//       mode 1  256x256 tile, 2 stages of 64 k, one workgroup per CU (128 FLOP per staged byte) — K >= 1536;
+//       mode 1  256x256 tile, 2 stages of 64 k, one workgroup per CU (128 FLOP per staged byte) — K >= 1024;
 //       mode 4  128x256 tile, ring of 3 stages of 32 k with two K-steps in flight, two workgroups per CU that hide
-//               each other's barriers and epilogues — short K (768 / 1024), where prologue + epilogue are 25-45 % of
+//               each other's barriers and epilogues — short K (768), where prologue + epilogue are 25-45 % of
 //               a tile's time.
 //     The DMA pieces are interleaved with the MFMA steps (an LDS-DMA instruction costs 60-180 issue cycles).  LDS rows
 //     are XOR-swizzled through the per-lane SOURCE address (the DMA image is lane-linear) so every ds_read_b128
@@ -319,11 +319,12 @@ bool gemm16_big_eligible(int dtype, const GemmParams& p) {
 hipError_t launch_gemm16_big(int dtype, const GemmParams& p, hipStream_t stream) {
     int mode = g_gemm16_big;
     if (mode == 3) {
-        // measured on MI355X (tools/gemm_bench.py, profiles/r01_gemm16_variants.md): long K loops amortise the serial
-        // prologue/epilogue of a one-workgroup-per-CU 256x256 tile and gain from its 128 FLOP per staged byte; short
-        // ones (K = 768 / 1024) are faster with two 128x256 workgroups per CU hiding each other's barriers and
+        // measured on MI355X (tools/gemm_bench.py, profiles/r01_gemm16_variants.md, and in the full forward with
+        // `bench.py --tune gemm16_big=1|4`): long K loops amortise the serial prologue/epilogue of a
+        // one-workgroup-per-CU 256x256 tile and gain from its 128 FLOP per staged byte; short ones (K = 768) are
+        // as fast or faster with two 128x256 workgroups per CU hiding each other's barriers and
         // epilogues
-        mode = p.K >= 1536 ? 1 : 4;
+        mode = p.K >= 1024 ? 1 : 4;
     }
     return dtype == BF16 ? big_mode<bf16_tag>(mode, p, stream) : big_mode<f16_tag>(mode, p, stream);
 }
