@@ -21,10 +21,15 @@ SAMPLE_RATE = 16000
 
 
 class UpstreamExpert(torch.nn.Module):
-    def __init__(self, model_config: str, **kwargs):
+    def __init__(self, model_config, **kwargs):
+        """``model_config``: path of a yaml file in the reference's baseline schema (``kaldi: {feat_type, fbank: {...}}``,
+        ``delta: {order, win_length}``, ``cmvn: {use_cmvn}``) or the already-parsed dict."""
         super().__init__()
-        with open(model_config, "r") as f:
-            self.config = yaml.load(f, Loader=yaml.FullLoader)
+        if isinstance(model_config, dict):
+            self.config = model_config
+        else:
+            with open(model_config, "r") as f:
+                self.config = yaml.load(f, Loader=yaml.FullLoader)
         if "kaldi" not in self.config or self.config["kaldi"].get("feat_type", "fbank") != "fbank":
             raise NotImplementedError("s3prl_amd implements the kaldi `fbank` baseline only (fbank / fbank_no_cmvn)")
         fb = dict(self.config["kaldi"].get("fbank", {}))
