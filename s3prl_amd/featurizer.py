@@ -69,37 +69,39 @@ class _WeightedSum(torch.autograd.Function):
 
 
 class Featurizer(nn.Module):
+    """See the module docstring; argument meaning as in the reference (nn/upstream.py:243-252)."""
+
     def __init__(self, upstream, layer_selections: Optional[List[int]] = None, normalize: bool = False):
         super().__init__()
-        assert len(set(upstream.hidden_sizes)) == 1
-        assert len(set(upstream.downsample_rates)) == 1
-        self._output_size = upstream.hidden_sizes[0]
-        self._downsample_rate = upstream.downsample_rates[0]
-        self.normalize = normalize
-        if upstream.num_layers > 1:
-            if layer_selections is not None:
-                assert upstream.num_layers >= len(layer_selections)
-                self.layer_selections = sorted(layer_selections)
-            else:
-                self.layer_selections = list(range(upstream.num_layers))
+        sizes, rates = set(upstream.hidden_sizes), set(upstream.downsample_rates)
+        if len(sizes) != 1 or len(rates) != 1:
+            raise AssertionError("every layer must share one hidden size and one stride")
+        (self._output_size,), (self._downsample_rate,) = sizes, rates
+        self.normalize = bool(normalize)
+        n_layers = int(upstream.num_layers)
+        if n_layers > 1:  # a single layer is passed through untouched and needs no weights
+            chosen = range(n_layers) if layer_selections is None else layer_selections
+            assert len(chosen) <= n_layers
+            self.layer_selections = sorted(chosen)
             self.weights = nn.Parameter(torch.zeros(len(self.layer_selections)))
 
     @property
     def output_size(self) -> int:
+        """hidden size of the weighted-sum output"""
         return self._output_size
 
     @property
     def downsample_rate(self) -> int:
+        """stride (in 16 kHz samples) of the weighted-sum output"""
         return self._downsample_rate
 
-    def _weighted_sum(self, all_hs, all_lens):
-        assert len(all_hs) == len(all_lens) > 1
-        norm_weights = F.softmax(self.weights, dim=-1)
-        return _WeightedSum.apply(norm_weights, self.normalize, *all_hs), all_lens[0]
-
     def forward(self, all_hs: List[torch.Tensor], all_lens: List[torch.Tensor]):
+        """``all_hs``: per-layer (B, T, D) tensors, ``all_lens``: per-layer (B,) lengths -> ((B, T, D), (B,))."""
         if len(all_hs) == 1:
             return all_hs[0], all_lens[0]
-        all_hs = [h for idx, h in enumerate(all_hs) if idx in self.layer_selections]
-        all_lens = [l for idx, l in enumerate(all_lens) if idx in self.layer_selections]
-        return self._weighted_sum(all_hs, all_lens)
+        keep = set(self.layer_selections)
+        picked_hs = [h for i, h in enumerate(all_hs) if i in keep]
+        picked_lens = [n for i, n in enumerate(all_lens) if i in keep]
+        assert len(picked_hs) == len(picked_lens) > 1
+        norm_weights = F.softmax(self.weights, dim=-1)
+        return _WeightedSum.apply(norm_weights, self.normalize, *picked_hs), picked_lens[0]
