@@ -192,7 +192,7 @@ template <> struct Mma16<f16_tag> {
 };
 
 template <typename T>
-__global__ __launch_bounds__(256) void attn_h16_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, 4) void attn_h16_kernel(AttnParams p) {
     __shared__ __attribute__((aligned(16))) u16 Ks[2 * KBUF16];
     __shared__ __attribute__((aligned(16))) u16 Vt[2 * VBUF16];
     const int b = blockIdx.z, head = blockIdx.y;
@@ -261,77 +261,74 @@ __global__ __launch_bounds__(256) void attn_h16_kernel(AttnParams p) {
         const u16* ks = Ks + (kt & 1) * KBUF16;
         const u16* vt = Vt + (kt & 1) * VBUF16;
 
-        f32x16 s[2];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[h][r] = 0.f;
-#pragma unroll
-            for (int st = 0; st < 4; ++st) {
-                const uint4 kf = *(const uint4*)(ks + (h * 32 + l31) * KS16 + st * 16 + 8 * half);
-                s[h] = Mma16<T>::run(kf, qf[st], s[h]);
-            }
-        }
+        // the 64 staged keys are consumed as two 32-key halves (scores -> softmax -> P.V per half): half the score
+        // registers of a 64-key pass, which keeps the kernel at <= 128 VGPRs (4 waves per SIMD); with the deferred
+        // max the second softmax pass costs nothing extra.
         // VALU, not the matrix pipe, bounds this kernel at the 16-bit MFMA rate, so the softmax is kept lean:
         // bias / mask passes only where they apply, and the running max is only raised (and O, l rescaled) when some
         // query's tile max exceeds it by more than 8 — softmax is invariant to the reference point, e^8 fits every
         // operand type, and after the first tile the rescale of the 32 O registers is almost never needed.
-        if (btab) {
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
+        for (int h = 0; h < 2; ++h) {
+            const int k0 = kt * KT16 + h * 32;
+            if (k0 >= valid) break;  // wave-uniform: the whole half is masked
+            f32x16 sc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const uint4 kf = *(const uint4*)(ks + (h * 32 + l31) * KS16 + st * 16 + 8 * half);
+                sc = Mma16<T>::run(kf, qf[st], sc);
+            }
+            if (btab) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int key = kt * KT16 + h * 32 + crow(r, half);
-                    if (key < p.T) s[h][r] += gate * btab[key - q_c + p.T - 1];
+                    const int key = k0 + crow(r, half);
+                    if (key < p.T) sc[r] += gate * btab[key - q_c + p.T - 1];
                 }
-        }
-        if (kt * KT16 + KT16 > valid) {
+            }
+            if (k0 + 32 > valid) {
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
+                for (int r = 0; r < 16; ++r) sc[r] = k0 + crow(r, half) < valid ? sc[r] : -INFINITY;
+            }
+            float mx = sc[0];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) s[h][r] = kt * KT16 + h * 32 + crow(r, half) < valid ? s[h][r] : -INFINITY;
-        }
-        float mx = fmaxf(s[0][0], s[1][0]);
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sc[r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            if (__any(mx > m_run + 8.f)) {
+                const float m_new = fmaxf(m_run, mx);
+                const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * 1.44269504088896340736f);
+                l_run *= alpha;
+                m_run = m_new;
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s[0][r], s[1][r]));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        if (__any(mx > m_run + 8.f)) {
-            const float m_new = fmaxf(m_run, mx);
-            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * 1.44269504088896340736f);
-            l_run *= alpha;
-            m_run = m_new;
+                for (int r = 0; r < 16; ++r) {
+                    o0[r] *= alpha;
+                    o1[r] *= alpha;
+                }
+            }
+            const float mneg = -m_run * 1.44269504088896340736f;
+            float ps = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                o0[r] *= alpha;
-                o1[r] *= alpha;
+                sc[r] = __builtin_amdgcn_exp2f(fmaf(sc[r], 1.44269504088896340736f, mneg));
+                ps += sc[r];
             }
-        }
-        const float mneg = -m_run * 1.44269504088896340736f;
-        float ps = 0.f;
+            l_run += ps;
+            // P^T as B operand: step u uses regs 8u..8u+7  <->  keys 32h + 16u + {0,1,2,3,8,9,10,11} + 4*half
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                s[h][r] = __builtin_amdgcn_exp2f(fmaf(s[h][r], 1.44269504088896340736f, mneg));
-                ps += s[h][r];
+            for (int u = 0; u < 2; ++u) {
+                uint4 pf;
+                pf.x = Cvt<T>::pack2(sc[8 * u + 0], sc[8 * u + 1]);
+                pf.y = Cvt<T>::pack2(sc[8 * u + 2], sc[8 * u + 3]);
+                pf.z = Cvt<T>::pack2(sc[8 * u + 4], sc[8 * u + 5]);
+                pf.w = Cvt<T>::pack2(sc[8 * u + 6], sc[8 * u + 7]);
+                const u16* v0 = vt + l31 * VS16 + 32 * h + 16 * u + 4 * half;
+                const u16* v1 = v0 + 32 * VS16;
+                const uint2 a00 = *(const uint2*)(v0), a01 = *(const uint2*)(v0 + 8);
+                const uint2 a10 = *(const uint2*)(v1), a11 = *(const uint2*)(v1 + 8);
+                o0 = Mma16<T>::run(make_uint4(a00.x, a00.y, a01.x, a01.y), pf, o0);
+                o1 = Mma16<T>::run(make_uint4(a10.x, a10.y, a11.x, a11.y), pf, o1);
             }
-        l_run += ps;
-        // P^T as B operand: step u uses regs 8(u&1)..+7 of s[u>>1]  <->  keys 16u + {0,1,2,3,8,9,10,11} + 4*half
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const f32x16& sv = s[u >> 1];
-            const int r0 = 8 * (u & 1);
-            uint4 pf;
-            pf.x = Cvt<T>::pack2(sv[r0 + 0], sv[r0 + 1]);
-            pf.y = Cvt<T>::pack2(sv[r0 + 2], sv[r0 + 3]);
-            pf.z = Cvt<T>::pack2(sv[r0 + 4], sv[r0 + 5]);
-            pf.w = Cvt<T>::pack2(sv[r0 + 6], sv[r0 + 7]);
-            const u16* v0 = vt + l31 * VS16 + 16 * u + 4 * half;
-            const u16* v1 = v0 + 32 * VS16;
-            const uint2 a00 = *(const uint2*)(v0), a01 = *(const uint2*)(v0 + 8);
-            const uint2 a10 = *(const uint2*)(v1), a11 = *(const uint2*)(v1 + 8);
-            o0 = Mma16<T>::run(make_uint4(a00.x, a00.y, a01.x, a01.y), pf, o0);
-            o1 = Mma16<T>::run(make_uint4(a10.x, a10.y, a11.x, a11.y), pf, o1);
         }
         if (kt + 1 < ntiles) A16_STORE((kt + 1) & 1)
         __syncthreads();
