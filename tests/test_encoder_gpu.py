@@ -296,3 +296,41 @@ def test_race_screen_repeated_runs_are_bit_identical(dtype):
         torch.cuda.synchronize()
         assert torch.equal(again, first)
     enc.close()
+
+
+def test_extract_feat_tool_dumps_reference_layouts(tmp_path):
+    """tools/extract_feat.py: wav files (8 kHz int16 stereo -> 16 kHz mono on the host) -> per-utterance
+    (num_layer, T_i, D) dumps like task/dump_feature.py, and the batch list like the reference's tools/extract_feat.py."""
+    import sys
+    import torch
+    from scipy.io import wavfile
+
+    sys.path.insert(0, str((__import__("pathlib").Path(__file__).resolve().parents[1] / "tools")))
+    import extract_feat as tool
+    from s3prl_amd.ckpt import save_checkpoint
+    from s3prl_amd.synth import named_config, synth_weights
+
+    cfg = named_config("tiny_hubert")
+    weights = synth_weights(cfg, 0)
+    ckpt = str(tmp_path / "tiny.pt")
+    save_checkpoint(ckpt, cfg, weights)
+    rng = np.random.default_rng(0)
+    paths = []
+    for i, n in enumerate((8000, 5000)):  # 1.0 s and 0.625 s at 8 kHz
+        pcm = (rng.standard_normal((n, 2)) * 3000).astype(np.int16)
+        paths.append(str(tmp_path / f"utt{i}.wav"))
+        wavfile.write(paths[-1], 8000, pcm)
+    out = tmp_path / "feats"
+    assert tool.main(["hubert_local", "--ckpt", ckpt, "--output_dir", str(out), "--wavs", *paths, "--per-utterance"]) == 0
+    wavs = [tool.load_wav_16k(p) for p in paths]
+    assert [len(w) for w in wavs] == [16000, 10000]
+    ref = O.forward(cfg, weights, wavs, dtype=np.float64)
+    for b, p in enumerate(paths):
+        feat = torch.load(str(out / f"utt{b}.pt"))
+        frames = min(cfg.num_frames(16000), round(len(wavs[b]) / 320))  # the Featurizer's length rule, capped at T
+        assert tuple(feat.shape) == (cfg.encoder_layers + 1, frames, cfg.encoder_embed_dim)
+        for l in range(cfg.encoder_layers + 1):
+            assert O.rel_err(feat[l].numpy(), ref[l][b, :frames]) < 5e-5
+    assert tool.main(["hubert_local", "--ckpt", ckpt, "--output_dir", str(out)]) == 0
+    hs = torch.load(str(out / "hubert_local.pt"))
+    assert isinstance(hs, list) and len(hs) == cfg.encoder_layers + 1 and hs[0].shape[0] == 2
