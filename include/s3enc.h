@@ -134,8 +134,9 @@ int s3enc_debug_tap(s3enc_handle h, const char* name, float* host_out, int64_t m
 
 /* Process-wide tuning knobs (kernel-variant selection for A/B measurements; results are unchanged):
  *   "gemm_variant": bit 0 = 64-byte K stages (else 128), bit 1 = LDS-DMA staging, bit 2 = no XCD-aware tile order;
- *   "gemm16_big":   large-tile kernel of the 16-bit modes: 0 off, 1 = 256x256 tiles (one workgroup per CU), 2 = 128x256,
- *                   4 = 128x256 with a 3-stage ring (two workgroups per CU), 3 = chosen by shape (default). */
+ *   "gemm16_big":   large-tile kernel of the 16-bit modes: 0 off, 1 = one workgroup per CU (256x256 or 192x256 tiles by CU
+ *                   utilisation; 5 / 6 force either), 2 = 128x256, 4 = 128x256 with a 3-stage ring (two workgroups per
+ *                   CU), 3 = chosen by shape (default). */
 int s3enc_set_tuning(const char* key, int32_t value);
 
 /* ---- single-kernel entry points (parity tests of each HIP kernel against the oracle) -------------------

@@ -1002,7 +1002,7 @@ int s3enc_set_tuning(const char* key, int32_t value) {
         return 0;
     }
     if (!strcmp(key, "gemm16_big")) {
-        if (value < 0 || value > 4) return fail("gemm16_big must be 0..4");
+        if (value < 0 || value > 6) return fail("gemm16_big must be 0..6");
         g_gemm16_big = value;
         return 0;
     }

@@ -293,7 +293,17 @@ hipError_t big_go(const GemmParams& p, hipStream_t stream) {
 template <typename T>
 hipError_t big_mode(int mode, const GemmParams& p, hipStream_t stream) {
     switch (mode) {
-        case 1: return big_go<T, 128, 128, 2, 2>(p, stream);  // 256x256, 128 KiB, one workgroup per CU
+        case 1: {  // one workgroup per CU, 2 stages of 64 k: 256x256 (128 KiB) or 192x256 (112 KiB) tiles — whichever
+                   // leaves fewer idle CU-rounds: time ~ ceil(tiles / 256 CUs) x tile rows (M = 15968, N = 768: 189 tiles
+                   // of 256 rows use 74 % of the CUs, 252 tiles of 192 rows use 98 % and are 3/4 as long)
+            const long nt = (p.N + 255) / 256;
+            const long t256 = ((p.M + 255) / 256) * nt * p.batches, t192 = ((p.M + 191) / 192) * nt * p.batches;
+            const long c256 = ((t256 + 255) / 256) * 256, c192 = ((t192 + 255) / 256) * 192;
+            // (the smaller tile is ~8 % less efficient per row: conv1 890 vs 840 TF at equal CU utilisation)
+            return c192 * 11 < c256 * 10 ? big_go<T, 96, 128, 2, 2>(p, stream) : big_go<T, 128, 128, 2, 2>(p, stream);
+        }
+        case 5: return big_go<T, 128, 128, 2, 2>(p, stream);  // 256x256 forced
+        case 6: return big_go<T, 96, 128, 2, 2>(p, stream);   // 192x256 forced
         case 2: return big_go<T, 64, 128, 2, 2>(p, stream);   // 128x256,  96 KiB, one per CU
         case 4: return big_go<T, 64, 64, 3, 4>(p, stream);    // 128x256,  72 KiB ring of 3, two per CU
         // measured and dropped (profiles/r01_gemm16_variants.md): 256x256 with 64-byte stages in a ring of 3 / 4,
@@ -304,7 +314,7 @@ hipError_t big_mode(int mode, const GemmParams& p, hipStream_t stream) {
 
 }  // namespace
 
-int g_gemm16_big = 3;  // 0 off, 3 = choose by shape, 1 / 2 / 4 = force one configuration (see big_mode)
+int g_gemm16_big = 3;  // 0 off, 3 = choose by shape, 1 / 2 / 4 / 5 / 6 = force one configuration (see big_mode)
 
 bool gemm16_big_eligible(int dtype, const GemmParams& p) {
     if (dtype == F32 || g_gemm16_big == 0) return false;
@@ -325,6 +335,10 @@ hipError_t launch_gemm16_big(int dtype, const GemmParams& p, hipStream_t stream)
         // as fast or faster with two 128x256 workgroups per CU hiding each other's barriers and
         // epilogues
         mode = p.K >= 1024 ? 1 : 4;
+        // a short-K GEMM that is exactly one round of 192-row tiles (out_proj at M = 15968, N = 768: 252 tiles on 256
+        // CUs) is faster there than as 375 128-row tiles on 512 slots: 31 vs 36 us
+        const long t192 = ((p.M + 191) / 192) * ((p.N + 255) / 256) * p.batches;
+        if (mode == 4 && t192 <= 256 && t192 >= 224) mode = 6;
     }
     return dtype == BF16 ? big_mode<bf16_tag>(mode, p, stream) : big_mode<f16_tag>(mode, p, stream);
 }

@@ -59,7 +59,7 @@ def test_gemm_variants(dtype, case, variant):
         _lib.check(lib.s3enc_set_tuning(b"gemm_variant", 3))
 
 
-@pytest.mark.parametrize("mode", [1, 2, 4, 0])
+@pytest.mark.parametrize("mode", [1, 2, 4, 5, 6, 0])
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("case", ["big_plain", "big_conv", "big_epilogue", "big_edge"])
 def test_gemm16_big_tiles(dtype, case, mode):

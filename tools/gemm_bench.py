@@ -31,7 +31,7 @@ def run(dtype, variants=None, rounds=5, shapes=None, reps=10):
     big = dtype != "fp32"
     if variants is None:
         # 16-bit modes: the large-tile kernel's configurations (gemm16_big; 0 = the 128x128 kernel); fp32: staging variants
-        variants = (0, 1, 2, 4, 5) if big else (1, 3, 0, 2)
+        variants = (0, 1, 4, 5, 6) if big else (1, 3, 0, 2)
     td = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[dtype]
     print(f"== {dtype}")
     for name, (nb, M, N, K, lda, rows) in SHAPES.items():
