@@ -291,7 +291,7 @@ template <typename T, int ROWB, bool GLDS, bool VEC>
 hipError_t gemm_go(const GemmParams& p, dim3 grid, hipStream_t stream) {
     constexpr int lds = 2 * (BM + BN) * ROWB;
     static_assert(lds >= 4 * 8192, "epilogue staging must fit");
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<T, ROWB, GLDS, VEC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t e = ensure_dynamic_lds<gemm_kernel<T, ROWB, GLDS, VEC>>(lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((gemm_kernel<T, ROWB, GLDS, VEC>), grid, dim3(256), lds, stream, p);
     return hipGetLastError();

@@ -283,7 +283,7 @@ hipError_t big_go(const GemmParams& p, hipStream_t stream) {
     static_assert(lds >= 2 * WN * 8192, "epilogue staging must fit");
     static_assert(lds * (WPE * 4 * 64 / NTHR) <= 160 * 1024, "workgroups per CU x LDS");
     auto kern = gemm16_big_kernel<T, WTM, ROWB, NST, WPE, WN>;
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t e = ensure_dynamic_lds<gemm16_big_kernel<T, WTM, ROWB, NST, WPE, WN>>(lds);
     if (e != hipSuccess) return e;
     dim3 grid(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.batches);
     hipLaunchKernelGGL(kern, grid, dim3(NTHR), lds, stream, p);

@@ -4,6 +4,20 @@
 
 namespace s3 {
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel instantiation, device) instead of once per launch:
+// the call costs several microseconds of host time, and a forward is ~290-560 launches.
+template <auto Kern>
+inline hipError_t ensure_dynamic_lds(int bytes) {
+    static int granted[64] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 64 && granted[dev] >= bytes) return hipSuccess;
+    e = hipFuncSetAttribute((const void*)Kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess && dev >= 0 && dev < 64) granted[dev] = bytes;
+    return e;
+}
+
 // ---- gemm.hip -----------------------------------------------------------------------------------------
 struct GemmParams {
     const void* A;  // (batches, M, K) rows at A + b*a_bs + m*lda (elements of the compute dtype)

@@ -108,7 +108,7 @@ template <int DG>
 hipError_t pc_launch(const PosConvParams& p, hipStream_t s) {
     const int rows = PC_TM + p.K - 1;
     const size_t lds = (size_t)(((rows * (DG + 8) + 3) & ~3) + 2 * DG * DG) * sizeof(float);
-    hipError_t e = hipFuncSetAttribute((const void*)posconv_kernel<DG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = ensure_dynamic_lds<posconv_kernel<DG>>((int)lds);
     if (e != hipSuccess) return e;
     dim3 grid((p.T + PC_TM - 1) / PC_TM, p.G, p.B);
     hipLaunchKernelGGL(posconv_kernel<DG>, grid, dim3(256), lds, s, p);
@@ -250,7 +250,7 @@ template <typename T, int DG>
 hipError_t pc16_launch(const PosConvParams& p, hipStream_t s) {
     const int ROWS = (P16_TM + p.K - 1 + 15) & ~15;
     const size_t lds = (size_t)(DG / 8) * ROWS * 16 + 2 * DG * 256;
-    hipError_t e = hipFuncSetAttribute((const void*)posconv16_kernel<T, DG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = ensure_dynamic_lds<posconv16_kernel<T, DG>>((int)lds);
     if (e != hipSuccess) return e;
     dim3 grid((p.T + P16_TM - 1) / P16_TM, p.G, p.B);
     hipLaunchKernelGGL((posconv16_kernel<T, DG>), grid, dim3(256), lds, s, p);
