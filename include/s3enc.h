@@ -33,7 +33,11 @@ enum { S3ENC_HUBERT = 0, S3ENC_WAV2VEC2 = 1, S3ENC_WAVLM = 2 };
 /* arithmetic type of the GEMM / attention operands; accumulation, norms, softmax, GELU and the residual
  * stream are always fp32 (the reference's Fp32GroupNorm / Fp32LayerNorm / fp32 softmax guards,
  * wav2vec2_model.py:1826-1853,1899-1900). */
-enum { S3ENC_F32 = 0, S3ENC_BF16 = 1, S3ENC_F16 = 2 };
+enum { S3ENC_F32 = 0, S3ENC_BF16 = 1, S3ENC_F16 = 2,
+       /* fp32 data flow (activations, norms, softmax, attention, positional conv exactly as S3ENC_F32) with the GEMMs
+        * computed as three bf16 MFMAs per product on split operands (x = hi + lo): ~1e-5 relative error per GEMM at
+        * 3/16 of the exact-fp32 matrix cost.  Opt-in; S3ENC_F32 stays the exact default. */
+       S3ENC_F32X3 = 3 };
 
 /* Hyper-parameters that select kernel variants.
  * Replaces: HubertConfig / HubertPretrainingConfig (upstream/hubert/hubert_model.py:33-278),
@@ -146,7 +150,8 @@ int s3enc_set_tuning(const char* key, int32_t value);
 /* out[b][m][n] = epilogue( sum_k A[b][m][k] * W[n][k] ):  A rows start at A + b*a_batch_stride + m*lda
  * (elements; lda < K expresses an overlapping strided-conv window), W is (N, K) row-major.
  * epilogue: + bias[n]; GELU if act; + residual (fp32, same indexing as out32); rows m >= row_limit[b] -> 0.
- * Writes out32 (fp32) and/or out16 (dtype) when non-NULL. */
+ * Writes out32 (fp32) and/or out16 (dtype) when non-NULL.  dtype S3ENC_F32X3: fp32 A / W / out32, three bf16 MFMAs per
+ * product (K % 32 == 0, M, N >= 128; synchronises). */
 int s3enc_op_gemm(int32_t dtype, const void* A, int64_t lda, int64_t a_batch_stride, const void* W,
                   const float* bias, int32_t M, int32_t N, int32_t K, int32_t batches, int32_t act,
                   const float* residual, const int32_t* row_limit, float* out32, void* out16, int64_t ldo,

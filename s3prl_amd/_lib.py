@@ -13,9 +13,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libs3enc.so")
 
 S3ENC_MAX_CONV = 16
-F32, BF16, F16 = 0, 1, 2
+F32, BF16, F16, F32X3 = 0, 1, 2, 3
 DTYPES = {"fp32": F32, "f32": F32, "float32": F32, "bf16": BF16, "bfloat16": BF16, "fp16": F16, "f16": F16,
-          "float16": F16}
+          "float16": F16, "fp32x3": F32X3, "f32x3": F32X3, "bf16x3": F32X3}
 FAMILY = {"hubert": 0, "wav2vec2": 1, "wavlm": 2}
 
 

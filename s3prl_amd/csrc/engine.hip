@@ -126,12 +126,25 @@ void pack_posconv(const std::vector<float>& w, int D, int G, int K, int dtype, s
                 }
 }
 
+// S3ENC_F32X3: upload the pair-packed bf16 hi / lo image of an (N, K) fp32 weight (K % 32 == 0, else left empty: that
+// GEMM then runs on the exact kernel)
+hipError_t upload_x3(DevBuf& d, const std::vector<float>& v, long N, long K) {
+    if (K % 32 || (long)v.size() < N * K) return hipSuccess;
+    std::vector<uint16_t> pk;
+    pack_x3(v.data(), N, K, pk);
+    hipError_t e = d.ensure(pk.size() * 2 + 16);
+    if (e != hipSuccess) return e;
+    return hipMemcpy(d.p, pk.data(), pk.size() * 2, hipMemcpyHostToDevice);
+}
+
 struct LayerW {
     DevBuf wqkv, bqkv, wo, bo, ln1g, ln1b, w1, b1, w2, b2, ln2g, ln2b;
+    DevBuf wqkv3, wo3, w13, w23;  // S3ENC_F32X3: pair-packed bf16 hi / lo images of the four weight matrices
     DevBuf grep_w, grep_b, grep_a;
 };
 struct ConvW {
     DevBuf w, bias, lng, lnb;  // w: conv0 fp32 [C][k]; conv>=1 compute dtype [C][k*Cin]
+    DevBuf w3;                 // S3ENC_F32X3: pair-packed image of w (conv >= 1)
     bool has_bias = false;
 };
 
@@ -146,10 +159,12 @@ struct s3enc_encoder {
     s3enc_config cfg;
     int device = 0;
     int dtype = F32;
+    bool x3 = false;  // S3ENC_F32X3
     int es = 4;  // element size of the compute dtype
     std::vector<ConvW> conv;
     DevBuf gn_g, gn_b;
     DevBuf fln_g, fln_b, proj_w, proj_b, pos_w, pos_b, eln_g, eln_b;
+    DevBuf proj_w3;  // S3ENC_F32X3
     std::vector<LayerW> layers;
     std::vector<float> rel_emb;  // host copy of relative_attention_bias.weight [buckets][H]
     DevBuf rel_table;
@@ -284,7 +299,7 @@ int check_config(const s3enc_config& c) {
     const int dg = c.embed_dim / c.conv_pos_groups;
     if (dg != 32 && dg != 48 && dg != 64) return fail("config: embed_dim/conv_pos_groups must be 32, 48 or 64");
     if (c.conv_pos < 1 || c.conv_pos > 256) return fail("config: conv_pos out of range");
-    if (c.compute_dtype < 0 || c.compute_dtype > 2) return fail("config: unknown compute_dtype");
+    if (c.compute_dtype < 0 || c.compute_dtype > 3) return fail("config: unknown compute_dtype");
     if (c.encoder_layers < 1) return fail("config: encoder_layers < 1");
     if (c.rel_pos && c.family != S3ENC_WAVLM) return fail("config: rel_pos is a WavLM feature");
     if (c.rel_pos && (c.num_buckets < 4 || c.max_distance <= c.num_buckets / 4))
@@ -320,7 +335,8 @@ int s3enc_create(const s3enc_config* cfg, const s3enc_tensor* tensors, int32_t n
     s3enc_encoder* e = new s3enc_encoder();
     e->cfg = *cfg;
     e->device = device;
-    e->dtype = cfg->compute_dtype;
+    e->x3 = cfg->compute_dtype == 3;  // S3ENC_F32X3: the fp32 data flow, GEMMs through gemm_x3.hip
+    e->dtype = e->x3 ? (int)F32 : cfg->compute_dtype;
     e->es = e->dtype == F32 ? 4 : 2;
     const s3enc_config& c = e->cfg;
     const int C = c.conv_dim, D = c.embed_dim, F = c.ffn_dim, H = c.heads;
@@ -355,6 +371,7 @@ int s3enc_create(const s3enc_config* cfg, const s3enc_tensor* tensors, int32_t n
                 for (int ci = 0; ci < cin; ++ci)
                     for (int j = 0; j < k; ++j) t2[((long)co * k + j) * cin + ci] = t[((long)co * cin + ci) * k + j];
             UP(upload_cvt(e->conv[i].w, t2, e->dtype));
+            if (e->x3) UP(upload_x3(e->conv[i].w3, t2, C, (long)k * cin));
         }
         if (c.conv_bias) {
             GET(p + ".0.bias", C, t);
@@ -379,6 +396,7 @@ int s3enc_create(const s3enc_config* cfg, const s3enc_tensor* tensors, int32_t n
     UP(upload_f32(e->fln_b, t));
     GET("post_extract_proj.weight", (long)D * C, t);
     UP(upload_cvt(e->proj_w, t, e->dtype));
+    if (e->x3) UP(upload_x3(e->proj_w3, t, D, C));
     GET("post_extract_proj.bias", D, t);
     UP(upload_f32(e->proj_b, t));
 
@@ -420,9 +438,11 @@ int s3enc_create(const s3enc_config* cfg, const s3enc_tensor* tensors, int32_t n
             for (int i = 0; i < D; ++i) bb[(long)s * D + i] = t2[i] * sc;
         }
         UP(upload_cvt(L.wqkv, w, e->dtype));
+        if (e->x3) UP(upload_x3(L.wqkv3, w, 3L * D, D));
         UP(upload_f32(L.bqkv, bb));
         GET(p + ".self_attn.out_proj.weight", (long)D * D, t);
         UP(upload_cvt(L.wo, t, e->dtype));
+        if (e->x3) UP(upload_x3(L.wo3, t, D, D));
         GET(p + ".self_attn.out_proj.bias", D, t);
         UP(upload_f32(L.bo, t));
         GET(p + ".self_attn_layer_norm.weight", D, t);
@@ -431,10 +451,12 @@ int s3enc_create(const s3enc_config* cfg, const s3enc_tensor* tensors, int32_t n
         UP(upload_f32(L.ln1b, t));
         GET(p + ".fc1.weight", (long)F * D, t);
         UP(upload_cvt(L.w1, t, e->dtype));
+        if (e->x3) UP(upload_x3(L.w13, t, F, D));
         GET(p + ".fc1.bias", F, t);
         UP(upload_f32(L.b1, t));
         GET(p + ".fc2.weight", (long)D * F, t);
         UP(upload_cvt(L.w2, t, e->dtype));
+        if (e->x3) UP(upload_x3(L.w23, t, D, F));
         GET(p + ".fc2.bias", D, t);
         UP(upload_f32(L.b2, t));
         GET(p + ".final_layer_norm.weight", D, t);
@@ -662,6 +684,7 @@ int forward_impl(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
         g.lda = (long)c.conv_stride[i] * C;
         g.a_bs = L[i - 1] * C;
         g.W = e->conv[i].w.p;
+        g.W_x3 = e->conv[i].w3.p;
         g.bias = e->conv[i].has_bias ? (const float*)e->conv[i].bias.p : nullptr;
         g.M = (int)L[i];
         g.N = C;
@@ -715,6 +738,7 @@ int forward_impl(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
         g.lda = C;
         g.a_bs = T * C;
         g.W = e->proj_w.p;
+        g.W_x3 = e->proj_w3.p;
         g.bias = (const float*)e->proj_b.p;
         g.M = (int)T;
         g.N = D;
@@ -796,6 +820,7 @@ int forward_impl(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
             g.A = a_in;
             g.lda = D;
             g.W = Lw.wqkv.p;
+            g.W_x3 = Lw.wqkv3.p;
             g.bias = (const float*)Lw.bqkv.p;
             g.M = (int)M;
             g.N = 3 * D;
@@ -826,6 +851,7 @@ int forward_impl(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
             g.A = attn;
             g.lda = D;
             g.W = Lw.wo.p;
+            g.W_x3 = Lw.wo3.p;
             g.bias = (const float*)Lw.bo.p;
             g.M = (int)M;
             g.N = D;
@@ -857,6 +883,7 @@ int forward_impl(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
             g.A = ffn_in;
             g.lda = D;
             g.W = Lw.w1.p;
+            g.W_x3 = Lw.w13.p;
             g.bias = (const float*)Lw.b1.p;
             g.M = (int)M;
             g.N = F;
@@ -873,6 +900,7 @@ int forward_impl(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
             g.A = hbuf;
             g.lda = F;
             g.W = Lw.w2.p;
+            g.W_x3 = Lw.w23.p;
             g.bias = (const float*)Lw.b2.p;
             g.M = (int)M;
             g.N = D;
@@ -1030,6 +1058,18 @@ int s3enc_op_gemm(int32_t dtype, const void* A, int64_t lda, int64_t a_batch_str
     g.out16 = out16;
     g.ldo = ldo;
     g.o_bs = o_batch_stride;
+    if (dtype == 3) {  // S3ENC_F32X3: fp32 operands; W is split into its pair-packed bf16 hi / lo image here
+        if (K % 32) return fail("s3enc_op_gemm: S3ENC_F32X3 needs K % 32 == 0");
+        std::vector<float> hw((size_t)N * K);
+        HIP_TRY(hipMemcpy(hw.data(), W, hw.size() * 4, hipMemcpyDeviceToHost));
+        DevBuf w3;
+        HIP_TRY(upload_x3(w3, hw, N, K));
+        g.W_x3 = w3.p;
+        if (!gemm_x3_eligible(g)) return fail("s3enc_op_gemm: shape / alignment not eligible for the S3ENC_F32X3 kernel");
+        HIP_TRY(launch_gemm(F32, g, (hipStream_t)stream));
+        HIP_TRY(hipStreamSynchronize((hipStream_t)stream));  // w3 is freed on return
+        return 0;
+    }
     HIP_TRY(launch_gemm(dtype, g, (hipStream_t)stream));
     return 0;
 }

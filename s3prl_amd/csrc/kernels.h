@@ -1,5 +1,8 @@
 // kernels.h — host-side launch interface of the HIP kernels (internal to libs3enc).
 #pragma once
+#include <cstring>
+#include <vector>
+
 #include "common.h"
 
 namespace s3 {
@@ -23,6 +26,7 @@ struct GemmParams {
     const void* A;  // (batches, M, K) rows at A + b*a_bs + m*lda (elements of the compute dtype)
     long lda, a_bs;
     const void* W;  // (N, K) row-major, compute dtype
+    const void* W_x3 = nullptr;  // fp32 mode only: the same matrix pair-packed as bf16 hi / lo (gemm_x3.hip), or null
     const float* bias;
     int M, N, K, batches;
     int act;                // 0 none, 1 erf-GELU
@@ -34,6 +38,10 @@ struct GemmParams {
     int variant = -1;  // tuning knob: -1 = library default (g_gemm_variant)
 };
 extern int g_gemm_variant;
+// gemm_x3.hip: fp32-class GEMM from three bf16 MFMAs per product (opt-in compute mode S3ENC_F32X3)
+bool gemm_x3_eligible(const GemmParams& p);
+hipError_t launch_gemm_x3(const GemmParams& p, hipStream_t stream);
+void pack_x3(const float* w, long N, long K, std::vector<uint16_t>& out);  // host: fp32 (N, K) -> pair-packed bf16 hi / lo
 // gemm16.hip: large-tile LDS-DMA kernel for the 16-bit modes (0 off, 1 = 256x256, 2 = 128x256, 3 = by tile count)
 extern int g_gemm16_big;
 bool gemm16_big_eligible(int dtype, const GemmParams& p);

@@ -334,3 +334,17 @@ def test_extract_feat_tool_dumps_reference_layouts(tmp_path):
     assert tool.main(["hubert_local", "--ckpt", ckpt, "--output_dir", str(out)]) == 0
     hs = torch.load(str(out / "hubert_local.pt"))
     assert isinstance(hs, list) and len(hs) == cfg.encoder_layers + 1 and hs[0].shape[0] == 2
+
+
+@pytest.mark.parametrize("name", ["tiny_hubert_pad", "tiny_wavlm_large_pad", "hubert_base_pseudo", "hubert_large_pseudo"])
+def test_fp32x3_split_precision_mode_close_to_reference(name, golden_loader):
+    """compute_dtype S3ENC_F32X3 (fp32 data flow, GEMMs as three bf16 MFMAs per product): two orders tighter than the
+    1e-3 target, one order looser than the exact fp32 mode."""
+    meta, cfg, weights, wavs, golden, _ = golden_loader(name)
+    enc = _encoder(cfg, weights, dtype="fp32x3")
+    hs = _run(enc, wavs)
+    assert np.isfinite(hs).all()
+    ts, cs = meta["t_stride"], meta["c_stride"]
+    errs = [O.rel_err(hs[l][:, ::ts, ::cs], golden[l]) for l in range(len(golden))]
+    assert max(errs) < 1e-4, f"{name}/fp32x3: per-layer rel-err {['%.2e' % e for e in errs]}"
+    enc.close()

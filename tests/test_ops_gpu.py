@@ -270,3 +270,58 @@ def test_posconv(dtype, shape):
     assert np.isfinite(got).all()
     err = O.rel_err(got - x, ref - x)  # error of the conv branch itself, not hidden behind the residual
     assert err < TOL[dtype], f"posconv {dtype}/{shape}: rel-err {err:.3e}"
+
+
+@pytest.mark.parametrize("case", ["big_plain", "big_conv", "big_epilogue", "x3_long"])
+def test_gemm_x3_split_precision(case):
+    """gemm_x3.hip: fp32 operands, every product rebuilt from three bf16 MFMAs (hi*hi + lo*hi + hi*lo).  Against the
+    float64 product of the UNROUNDED fp32 operands the error must sit at the 1e-5 level (vs 3e-3 for plain bf16 and
+    1e-6 for the exact kernel), on multi-tile shapes with ragged edges, overlapping conv rows and the full epilogue."""
+    torch = _torch()
+    from s3prl_amd import _lib
+
+    lib = _lib.load()
+    rng = np.random.default_rng(zlib.crc32(f"x3/{case}".encode()))
+    act, use_res, use_lim = 0, False, False
+    Cc, Lin = 128, 1101
+    if case == "big_plain":
+        batches, M, N, K, lda = 1, 700, 516, 320, 320
+    elif case == "big_conv":
+        M = (Lin - 3) // 2 + 1
+        batches, N, K, lda = 3, 256, 3 * Cc, 2 * Cc
+        act = 1
+    elif case == "big_epilogue":
+        batches, M, N, K, lda = 2, 530, 264, 128, 136
+        act, use_res, use_lim = 1, True, True
+    else:
+        batches, M, N, K, lda = 1, 1000, 768, 3072, 3072
+    a_bs = Lin * Cc if case == "big_conv" else M * lda
+    A = rng.standard_normal((batches, a_bs)).astype(np.float32)
+    W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    res = rng.standard_normal((batches, M, N)).astype(np.float32)
+    lim = np.array([M - 5, M // 2, M][:batches], dtype=np.int32)
+    ref = np.empty((batches, M, N))
+    lin = np.empty((batches, M, N))
+    for b in range(batches):
+        rows = np.stack([A[b, m * lda:m * lda + K] for m in range(M)]).astype(np.float64)
+        y = rows @ W.astype(np.float64).T + bias
+        lin[b] = y
+        if act:
+            y = O.gelu(y)
+        if use_res:
+            y = y + res[b]
+        if use_lim:
+            y[lim[b]:] = 0
+        ref[b] = y
+    dA, dW, dbias, dres, dlim = _dev(A), _dev(W), _dev(bias), _dev(res), torch.from_numpy(lim).cuda()
+    out = torch.full((batches, M, N), float("nan"), device="cuda")
+    rc = lib.s3enc_op_gemm(3, _ptr(dA), lda, a_bs, _ptr(dW), _ptr(dbias), M, N, K, batches, act,
+                           _ptr(dres) if use_res else None, _ptr(dlim) if use_lim else None, _ptr(out), None, N, M * N, None)
+    _lib.check(rc, "s3enc_op_gemm x3")
+    got = out.cpu().numpy()
+    assert np.isfinite(got).all()
+    err = O.rel_err(got, ref)
+    assert err < 3e-5, f"x3 gemm {case}: rel-err {err:.3e}"
+    bad = np.abs(got - ref) > 3e-4 * (1 + np.abs(ref))
+    assert not bad.any(), f"{bad.sum()} elements off, first at {np.argwhere(bad)[0]}"

@@ -75,6 +75,12 @@ if __name__ == "__main__":
                     stage_report(n, d)
                 except Exception as ex:
                     print(f"!! {n}/{d}: {type(ex).__name__}: {ex}")
+    if "stagesx3" in what:
+        for n in ["tiny_hubert_pad", "hubert_base_pseudo", "hubert_large_pseudo", "wavlm_large_pseudo"]:
+            try:
+                stage_report(n, "fp32x3")
+            except Exception as ex:
+                print(f"!! {n}/fp32x3: {type(ex).__name__}: {ex}")
     if "time" in what:
         for d in ("fp32", "bf16", "fp16"):
             try:
