@@ -82,6 +82,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=INT",
                     help="s3enc_set_tuning knob for A/B runs (e.g. gemm16_big=4); results are unchanged")
+    ap.add_argument("--no-other-modes", action="store_true",
+                    help="skip the short side measurement of the other operand modes (fp32x3, bf16) in the default run")
     ap.add_argument("--no-profile", action="store_true", help="no per-kernel HIP events in the timed region (A/B of their cost)")
     ap.add_argument("--cpu-sample", type=int, default=32, help="utterances of the workload timed on the CPU oracle")
     ap.add_argument("--parity-sample", type=int, default=2, help="utterances checked against the numpy oracle")
@@ -282,6 +284,27 @@ def main():
             line["parity"] = {"max_layer_rel_err_vs_numpy_oracle": float(f"{err_n:.3e}"), "numpy_sample": f"{npar} utterances",
                               "max_layer_rel_err_vs_torch_oracle": float(f"{err_t:.3e}"), "torch_sample": f"{ns} utterances",
                               "tolerance": 1e-3}
+            if not args.no_other_modes and not args.mixed:
+                # side measurement (same workload, same inputs, untimed for the headline): the opt-in operand modes,
+                # each with its own parity against the torch restatement of the full batch
+                other = {}
+                for mode in [m for m in ("fp32x3", "bf16") if m != args.dtype]:
+                    enc2 = HipEncoder(cfg, weights, dtype=mode, device=dev.index)
+                    out2 = torch.empty_like(out)
+                    for _ in range(3):
+                        enc2.forward(wavs, out=out2)
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    for _ in range(10):
+                        enc2.forward(wavs, out=out2)
+                    torch.cuda.synchronize()
+                    dt = (time.perf_counter() - t1) / 10
+                    err = max(O.rel_err(out2[l][:ns].cpu().numpy(), ref_t[l].numpy()) for l in range(NL + 1))
+                    other[mode] = {"value": round(B * T / dt, 1), "ms_per_step": round(dt * 1e3, 3),
+                                   "max_layer_rel_err_vs_torch_oracle": float(f"{err:.3e}")}
+                    enc2.close()
+                    del out2
+                line["other_modes"] = other
         print(json.dumps(line))
     enc.close()
     if world > 1:
