@@ -10,6 +10,7 @@ mkdir -p $out
 python bench.py > $out/bench_fp32.json 2> $out/bench_fp32.err
 python bench.py --dtype bf16 --no-cpu-baseline > $out/bench_bf16.json 2>/dev/null
 python bench.py --dtype fp16 --no-cpu-baseline > $out/bench_fp16.json 2>/dev/null
+python bench.py --dtype fp32x3 --no-cpu-baseline > $out/bench_fp32x3.json 2>/dev/null
 python bench.py --model wav2vec2_base --no-cpu-baseline --steps 10 --warmup 2 > $out/bench_cfg1_wav2vec2_base_fp32.json 2>/dev/null
 python bench.py --model hubert_base --dtype bf16 --batch 64 --no-cpu-baseline --steps 10 --warmup 2 > $out/bench_cfg2_hubert_base_b64_bf16.json 2>/dev/null
 python bench.py --model hubert_large --dtype bf16 --no-cpu-baseline --steps 5 --warmup 1 > $out/bench_cfg3_hubert_large_bf16.json 2>/dev/null
