@@ -82,6 +82,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=INT",
                     help="s3enc_set_tuning knob for A/B runs (e.g. gemm16_big=4); results are unchanged")
+    ap.add_argument("--backend", default="nccl",
+                    help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to exercise the N-rank path on a "
+                         "box with fewer GPUs than ranks: ranks then share devices)")
     ap.add_argument("--no-other-modes", action="store_true",
                     help="skip the short side measurement of the other operand modes (fp32x3, bf16) in the default run")
     ap.add_argument("--no-profile", action="store_true", help="no per-kernel HIP events in the timed region (A/B of their cost)")
@@ -105,8 +108,12 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        local_rank %= max(1, torch.cuda.device_count())
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
     else:
         torch.cuda.set_device(0)
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
