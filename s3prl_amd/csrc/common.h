@@ -57,6 +57,20 @@ template <> struct Cvt<f16_tag> {
     static __device__ __forceinline__ float from(u16 h) { return f16_to_f32(h); }
 };
 
+// Split-precision operands (gemm_x3.hip, posconv x3): 8 fp32 (two float4) -> bf16x8 hi and bf16x8 lo with
+// x = hi + lo + r, |r| <= 2^-17 |x|  (hi = bf16(x) by v_cvt_pk_bf16_f32, lo = bf16(x - hi))
+__device__ __forceinline__ void split8(const float4& x0, const float4& x1, uint4& hi, uint4& lo) {
+    auto pair = [](float a, float b, unsigned& h, unsigned& l) {
+        h = Cvt<bf16_tag>::pack2(a, b);
+        const float ha = __uint_as_float(h << 16), hb = __uint_as_float(h & 0xffff0000u);
+        l = Cvt<bf16_tag>::pack2(a - ha, b - hb);
+    };
+    pair(x0.x, x0.y, hi.x, lo.x);
+    pair(x0.z, x0.w, hi.y, lo.y);
+    pair(x1.x, x1.y, hi.z, lo.z);
+    pair(x1.z, x1.w, hi.w, lo.w);
+}
+
 // erf-GELU in fp32: nn.GELU() / F.gelu(x.float()) on the reference path.
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 

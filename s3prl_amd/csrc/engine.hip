@@ -137,6 +137,21 @@ hipError_t upload_x3(DevBuf& d, const std::vector<float>& v, long N, long K) {
     return hipMemcpy(d.p, pk.data(), pk.size() * 2, hipMemcpyHostToDevice);
 }
 
+// S3ENC_F32X3 positional conv: the 16-bit layout [G][Dg][K*Dg] as a bf16 hi image followed by the lo image
+hipError_t upload_posconv_x3(DevBuf& d, const std::vector<float>& w, int D, int G, int K) {
+    std::vector<float> lay;
+    pack_posconv(w, D, G, K, BF16, lay);
+    std::vector<uint16_t> img(lay.size() * 2);
+    for (size_t i = 0; i < lay.size(); ++i) {
+        const uint16_t h = h_bf16(lay[i]);
+        img[i] = h;
+        img[lay.size() + i] = h_bf16(lay[i] - h_from16(h, BF16));
+    }
+    hipError_t e = d.ensure(img.size() * 2 + 16);
+    if (e != hipSuccess) return e;
+    return hipMemcpy(d.p, img.data(), img.size() * 2, hipMemcpyHostToDevice);
+}
+
 struct LayerW {
     DevBuf wqkv, bqkv, wo, bo, ln1g, ln1b, w1, b1, w2, b2, ln2g, ln2b;
     DevBuf wqkv3, wo3, w13, w23;  // S3ENC_F32X3: pair-packed bf16 hi / lo images of the four weight matrices
@@ -164,7 +179,7 @@ struct s3enc_encoder {
     std::vector<ConvW> conv;
     DevBuf gn_g, gn_b;
     DevBuf fln_g, fln_b, proj_w, proj_b, pos_w, pos_b, eln_g, eln_b;
-    DevBuf proj_w3;  // S3ENC_F32X3
+    DevBuf proj_w3, pos_w3;  // S3ENC_F32X3
     std::vector<LayerW> layers;
     std::vector<float> rel_emb;  // host copy of relative_attention_bias.weight [buckets][H]
     DevBuf rel_table;
@@ -414,6 +429,7 @@ int s3enc_create(const s3enc_config* cfg, const s3enc_tensor* tensors, int32_t n
             for (int k = 0; k < K; ++k) v[i * K + k] = (float)(v[i * K + k] * nrm[k]);
         pack_posconv(v, D, G, K, e->dtype, t2);
         UP(upload_cvt(e->pos_w, t2, e->dtype));
+        if (e->x3) UP(upload_posconv_x3(e->pos_w3, v, D, G, K));
         GET("encoder.pos_conv.0.bias", D, t);
         UP(upload_f32(e->pos_b, t));
     }
@@ -766,7 +782,12 @@ int forward_impl(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
         p.G = c.conv_pos_groups;
         p.K = c.conv_pos;
         Prof pr(e, st, "posconv", 2.0 * M * D * (D / p.G) * p.K, (double)M * D * 8 + (double)D * (D / p.G) * p.K * 4);
-        HIP_TRY(dt == F32 ? launch_posconv(p, st) : launch_posconv16(dt, p, st));
+        if (e->x3) {
+            p.w = e->pos_w3.p;
+            HIP_TRY(launch_posconv16(3, p, st));
+        } else {
+            HIP_TRY(dt == F32 ? launch_posconv(p, st) : launch_posconv16(dt, p, st));
+        }
         e->taps["posconv"] = {p.out, M * D, F32};
     }
     if (!prel) {
@@ -1101,9 +1122,13 @@ int s3enc_op_posconv(int32_t dtype, const float* x, const float* w_host, const f
     if (G <= 0 || D % G) return fail("s3enc_op_posconv: D must be a multiple of groups");
     const int Dg = D / G;
     std::vector<float> w(w_host, w_host + (size_t)D * Dg * K), packed;
-    pack_posconv(w, D, G, K, dtype, packed);
     DevBuf dw;
-    HIP_TRY(upload_cvt(dw, packed, dtype));
+    if (dtype == 3) {
+        HIP_TRY(upload_posconv_x3(dw, w, D, G, K));
+    } else {
+        pack_posconv(w, D, G, K, dtype, packed);
+        HIP_TRY(upload_cvt(dw, packed, dtype));
+    }
     PosConvParams p{};
     p.x = x;
     p.w = dw.p;

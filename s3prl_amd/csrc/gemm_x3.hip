@@ -7,8 +7,9 @@
 // and the product is rebuilt from three bf16 MFMAs with fp32 accumulation,
 //     a*w  ~=  a_hi*w_hi + a_lo*w_hi + a_hi*w_lo          (dropped: a_lo*w_lo ~ 2^-18, truncation r ~ 2^-17)
 // i.e. a relative error of ~1e-5 per product (random sign) at 3/16 of the fp32 MFMA cost.  No range is lost (bf16 has
-// the fp32 exponent).  It is an OPT-IN mode (compute_dtype S3ENC_F32X3): activations, residual stream, norms, softmax,
-// attention and the positional conv stay exactly as in the fp32 mode — only the GEMMs change.
+// the fp32 exponent).  It is an OPT-IN mode (compute_dtype S3ENC_F32X3): activations, residual stream, norms, softmax
+// and attention stay exactly as in the fp32 mode — only the GEMMs (here) and the positional conv (posconv.hip, same
+// split) change.
 //   * A (activations) stays fp32 in memory and in LDS; the split happens on the fragment registers
 //     (v_cvt_pk_bf16_f32 + 2 v_sub + a shift / mask per pair: ~100 VALU per 24 MFMAs, hidden beside them).
 //   * W is split once at pack time into a "pair-packed" image with the same bytes and the same addressing as fp32:
@@ -31,19 +32,6 @@ constexpr int XBN = 256, XROWB = 128;  // tile columns; bytes per row per stage 
 
 __device__ __forceinline__ f32x16 mma_bf16(const uint4& a, const uint4& b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
-
-// 8 fp32 (two float4) -> bf16x8 hi and bf16x8 lo
-__device__ __forceinline__ void split8(const float4& x0, const float4& x1, uint4& hi, uint4& lo) {
-    auto pair = [](float a, float b, unsigned& h, unsigned& l) {
-        h = Cvt<bf16_tag>::pack2(a, b);
-        const float ha = __uint_as_float(h << 16), hb = __uint_as_float(h & 0xffff0000u);
-        l = Cvt<bf16_tag>::pack2(a - ha, b - hb);
-    };
-    pair(x0.x, x0.y, hi.x, lo.x);
-    pair(x0.z, x0.w, hi.y, lo.y);
-    pair(x1.x, x1.y, hi.z, lo.z);
-    pair(x1.z, x1.w, hi.w, lo.w);
 }
 
 template <int WTM>

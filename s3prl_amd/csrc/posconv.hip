@@ -141,20 +141,28 @@ template <> struct Mma16x16<f16_tag> {
     }
 };
 
-template <typename T, int DG>
+// X3: split-precision variant of the fp32x3 mode (S3ENC_F32X3): the fp32 window is split into a bf16 hi and a bf16 lo
+// plane, W arrives as a hi and a lo image ([G][Dg][K*Dg] each, lo after hi), every product is
+// a_hi*w_hi + a_lo*w_hi + a_hi*w_lo (~1e-5 relative, see gemm_x3.hip); 128 frames per workgroup (two planes of LDS),
+// libm erff GELU like the fp32 kernel.
+template <typename T, int DG, bool X3>
 __global__ __launch_bounds__(256) void posconv16_kernel(PosConvParams p) {
     constexpr int NT = DG / 16;  // 16-wide output-channel tiles
     constexpr int CH = DG / 8;   // 16-byte chunks per frame
-    constexpr int NLW = DG * 16 / 256;  // 16-byte W pieces per thread per stage
-    constexpr int WBUF = DG * 256;      // bytes per W stage
+    constexpr int NLW = DG * 16 / 256;  // 16-byte W pieces per thread per stage and plane
+    constexpr int WBUF = DG * 256;      // bytes per W stage and plane
+    constexpr int NS = X3 ? 2 : 1;      // operand planes (hi, lo)
+    constexpr int TMF = X3 ? 128 : P16_TM;  // output frames per workgroup
+    constexpr int MT = TMF / 64;            // 16-frame M tiles per wave
     extern __shared__ __attribute__((aligned(16))) char lds16[];
     const int K = p.K;
-    const int ROWS = (P16_TM + K - 1 + 15) & ~15;  // window rows, padded so chunk planes start on the same bank
+    const int ROWS = (TMF + K - 1 + 15) & ~15;  // window rows, padded so chunk planes start on the same bank
+    const size_t WIN = (size_t)CH * ROWS * 16;  // bytes of one window plane
     char* win = lds16;
-    char* wl = lds16 + (size_t)CH * ROWS * 16;
+    char* wl = lds16 + NS * WIN;  // [plane][buffer][WBUF]
 
     const int b = blockIdx.z, g = blockIdx.y;
-    const int t0 = blockIdx.x * P16_TM;
+    const int t0 = blockIdx.x * TMF;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, kgrp = lane >> 4;
     const int pad = K / 2;
@@ -163,64 +171,79 @@ __global__ __launch_bounds__(256) void posconv16_kernel(PosConvParams p) {
     // ---- W stage loader: piece e = (row n, chunk c); LDS slot of chunk c in row n is c ^ (n & 15).
     //      (macros, not lambdas: a by-reference capture of the register array ends up in scratch memory) ----
     const char* wg = (const char*)p.w + (long)g * DG * Ktot * 2;
-    u32x4 wreg[NLW];  // native vectors: an array of HIP uint4 structs held across the loop is left in scratch memory
-#define P16_WLOAD(kc_)                                                                                   \
-    _Pragma("unroll") for (int i_ = 0; i_ < NLW; ++i_) {                                               \
-        const int e_ = tid + 256 * i_, n_ = e_ >> 4, c_ = e_ & 15;                                     \
-        wreg[i_] = *(const u32x4*)(wg + ((long)n_ * Ktot + (long)(kc_) * P16_KC + c_ * 8) * 2);        \
+    const long plane_bytes = (long)p.G * DG * Ktot * 2;  // X3: the lo image follows the hi image
+    u32x4 wreg[NS][NLW];  // native vectors: an array of HIP uint4 structs held across the loop is left in scratch memory
+#define P16_WLOAD(kc_)                                                                                        \
+    _Pragma("unroll") for (int s_ = 0; s_ < NS; ++s_) _Pragma("unroll") for (int i_ = 0; i_ < NLW; ++i_) {  \
+        const int e_ = tid + 256 * i_, n_ = e_ >> 4, c_ = e_ & 15;                                          \
+        wreg[s_][i_] = *(const u32x4*)(wg + s_ * plane_bytes + ((long)n_ * Ktot + (long)(kc_) * P16_KC + c_ * 8) * 2); \
     }
-#define P16_WSTORE(buf_)                                                                                 \
-    _Pragma("unroll") for (int i_ = 0; i_ < NLW; ++i_) {                                               \
-        const int e_ = tid + 256 * i_, n_ = e_ >> 4, c_ = e_ & 15;                                     \
-        *(u32x4*)(wl + (buf_) * WBUF + (n_ * 16 + (c_ ^ (n_ & 15))) * 16) = wreg[i_];                  \
+#define P16_WSTORE(buf_)                                                                                      \
+    _Pragma("unroll") for (int s_ = 0; s_ < NS; ++s_) _Pragma("unroll") for (int i_ = 0; i_ < NLW; ++i_) {  \
+        const int e_ = tid + 256 * i_, n_ = e_ >> 4, c_ = e_ & 15;                                          \
+        *(u32x4*)(wl + (s_ * 2 + (buf_)) * WBUF + (n_ * 16 + (c_ ^ (n_ & 15))) * 16) = wreg[s_][i_];       \
     }
     P16_WLOAD(0)
 
-    // ---- input window: fp32 -> 16-bit, chunk-major ----
+    // ---- input window: fp32 -> 16-bit (X3: hi and lo planes), chunk-major ----
     const float* xg = p.x + (long)b * p.T * p.D + g * DG;
-    const int rows = P16_TM + K - 1;
+    const int rows = TMF + K - 1;
     for (int idx = tid; idx < ROWS * CH; idx += 256) {
         const int f = idx % ROWS, cc = idx / ROWS;
         const int ts = t0 + f - pad;
-        uint4 h = make_uint4(0, 0, 0, 0);
+        uint4 h = make_uint4(0, 0, 0, 0), l = make_uint4(0, 0, 0, 0);
         if (f < rows && ts >= 0 && ts < p.T) {
             const float4 v0 = *(const float4*)(xg + (long)ts * p.D + cc * 8);
             const float4 v1 = *(const float4*)(xg + (long)ts * p.D + cc * 8 + 4);
-            h.x = Cvt<T>::pack2(v0.x, v0.y);
-            h.y = Cvt<T>::pack2(v0.z, v0.w);
-            h.z = Cvt<T>::pack2(v1.x, v1.y);
-            h.w = Cvt<T>::pack2(v1.z, v1.w);
+            if constexpr (X3) {
+                split8(v0, v1, h, l);
+            } else {
+                h.x = Cvt<T>::pack2(v0.x, v0.y);
+                h.y = Cvt<T>::pack2(v0.z, v0.w);
+                h.z = Cvt<T>::pack2(v1.x, v1.y);
+                h.w = Cvt<T>::pack2(v1.z, v1.w);
+            }
         }
         *(uint4*)(win + ((size_t)cc * ROWS + f) * 16) = h;
+        if constexpr (X3) *(uint4*)(win + WIN + ((size_t)cc * ROWS + f) * 16) = l;
     }
     P16_WSTORE(0)
     __syncthreads();
 
-    f32x4 acc[4][NT];
+    f32x4 acc[MT][NT];
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nkc = (int)(Ktot / P16_KC);  // = DG
-    const int arow = wave * 64 + l15;
+    const int arow = wave * (TMF / 4) + l15;
     for (int kc = 0; kc < nkc; ++kc) {
         if (kc + 1 < nkc) { P16_WLOAD(kc + 1) }
-        const char* wb = wl + (kc & 1) * WBUF;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int idx = kc * 16 + s * 4 + kgrp;  // 16-byte chunk index along k
             const int j = idx / CH, cc = idx - j * CH;
-            const char* ap = win + ((size_t)cc * ROWS + arow + j) * 16;
-            uint4 fa[4], fb[NT];
+            const size_t aoff = ((size_t)cc * ROWS + arow + j) * 16;
+            uint4 fa[NS][MT], fb[NS][NT];
 #pragma unroll
-            for (int n = 0; n < NT; ++n) fb[n] = *(const uint4*)(wb + ((n * 16 + l15) * 16 + ((s * 4 + kgrp) ^ l15)) * 16);
+            for (int pl = 0; pl < NS; ++pl) {
+                const char* wb = wl + (pl * 2 + (kc & 1)) * WBUF;
 #pragma unroll
-            for (int m = 0; m < 4; ++m) fa[m] = *(const uint4*)(ap + m * 256);
+                for (int n = 0; n < NT; ++n) fb[pl][n] = *(const uint4*)(wb + ((n * 16 + l15) * 16 + ((s * 4 + kgrp) ^ l15)) * 16);
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
+                for (int m = 0; m < MT; ++m) fa[pl][m] = *(const uint4*)(win + pl * WIN + aoff + m * 256);
+            }
 #pragma unroll
-                for (int n = 0; n < NT; ++n) acc[m][n] = Mma16x16<T>::run(fa[m], fb[n], acc[m][n]);
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    if constexpr (X3) {
+                        acc[m][n] = Mma16x16<T>::run(fa[1][m], fb[0][n], acc[m][n]);
+                        acc[m][n] = Mma16x16<T>::run(fa[0][m], fb[1][n], acc[m][n]);
+                    }
+                    acc[m][n] = Mma16x16<T>::run(fa[0][m], fb[0][n], acc[m][n]);
+                }
         }
         if (kc + 1 < nkc) { P16_WSTORE((kc + 1) & 1) }
         __syncthreads();
@@ -234,35 +257,38 @@ __global__ __launch_bounds__(256) void posconv16_kernel(PosConvParams p) {
         const int c = g * DG + n * 16 + l15;
         const float bias = p.bias[c];
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int t = t0 + wave * 64 + m * 16 + 4 * kgrp + r;
+                const int t = t0 + wave * (TMF / 4) + m * 16 + 4 * kgrp + r;
                 if (t < p.T) {
                     const long o = ((long)b * p.T + t) * p.D + c;
-                    p.out[o] = p.x[o] + gelu_fast(acc[m][n][r] + bias);
+                    const float y = acc[m][n][r] + bias;
+                    p.out[o] = p.x[o] + (X3 ? gelu_erf(y) : gelu_fast(y));
                 }
             }
     }
 }
 
-template <typename T, int DG>
+template <typename T, int DG, bool X3>
 hipError_t pc16_launch(const PosConvParams& p, hipStream_t s) {
-    const int ROWS = (P16_TM + p.K - 1 + 15) & ~15;
-    const size_t lds = (size_t)(DG / 8) * ROWS * 16 + 2 * DG * 256;
-    hipError_t e = ensure_dynamic_lds<posconv16_kernel<T, DG>>((int)lds);
+    constexpr int NS = X3 ? 2 : 1, TMF = X3 ? 128 : P16_TM;
+    const int ROWS = (TMF + p.K - 1 + 15) & ~15;
+    const size_t lds = (size_t)NS * (DG / 8) * ROWS * 16 + (size_t)NS * 2 * DG * 256;
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    hipError_t e = ensure_dynamic_lds<posconv16_kernel<T, DG, X3>>((int)lds);
     if (e != hipSuccess) return e;
-    dim3 grid((p.T + P16_TM - 1) / P16_TM, p.G, p.B);
-    hipLaunchKernelGGL((posconv16_kernel<T, DG>), grid, dim3(256), lds, s, p);
+    dim3 grid((p.T + TMF - 1) / TMF, p.G, p.B);
+    hipLaunchKernelGGL((posconv16_kernel<T, DG, X3>), grid, dim3(256), lds, s, p);
     return hipGetLastError();
 }
 
-template <typename T>
+template <typename T, bool X3 = false>
 hipError_t pc16_dispatch(const PosConvParams& p, int dg, hipStream_t s) {
     switch (dg) {
-        case 32: return pc16_launch<T, 32>(p, s);
-        case 48: return pc16_launch<T, 48>(p, s);
-        case 64: return pc16_launch<T, 64>(p, s);
+        case 32: return pc16_launch<T, 32, X3>(p, s);
+        case 48: return pc16_launch<T, 48, X3>(p, s);
+        case 64: return pc16_launch<T, 64, X3>(p, s);
     }
     return hipErrorInvalidValue;
 }
@@ -276,6 +302,7 @@ hipError_t launch_posconv16(int dtype, const PosConvParams& p, hipStream_t s) {
     if (dg * p.G != p.D || (p.K & 1) || ((long)p.K * dg) % P16_KC) return hipErrorInvalidValue;
     if (dtype == BF16) return pc16_dispatch<bf16_tag>(p, dg, s);
     if (dtype == F16) return pc16_dispatch<f16_tag>(p, dg, s);
+    if (dtype == 3) return pc16_dispatch<bf16_tag, true>(p, dg, s);  // S3ENC_F32X3: p.w = bf16 hi image followed by the lo image
     return hipErrorInvalidValue;
 }
 
