@@ -351,6 +351,179 @@ __global__ __launch_bounds__(256, 4) void attn_h16_kernel(AttnParams p) {
 
 // WavLM gate from the layer input split into heads (wavlm/modules.py:535-549):
 //   g = sigmoid( sum4( grep_linear(x_head) ) ) -> (a, b);  gate = a * (b * grep_a[h] - 1) + 2
+// ---- fp32x3 mode (S3ENC_F32X3): fp32 q|k|v in, fp32 out, both matrix products on split bf16 operands ------------------
+// S^T = K Q^T and O^T += V^T P^T are rebuilt from three bf16 MFMAs each on x = hi + lo operands (see gemm_x3.hip):
+// K, V are split while they are staged into LDS (hi and lo tiles), Q once into registers, the probabilities P on the
+// score registers.  Same structure as attn_h16_kernel (64 staged keys consumed as two 32-key halves, double-buffered
+// LDS, register prefetch, deferred max); the softmax itself is fp32 as everywhere.  1/5 of the exact kernel's matrix time.
+__global__ __launch_bounds__(256, 3) void attn_x3_kernel(AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char dyn_x3[];
+    u16* Ks = (u16*)dyn_x3;                       // [plane][buffer][KBUF16]
+    u16* Vt = Ks + 4 * KBUF16;                    // [plane][buffer][VBUF16]
+    float* bias_s = (float*)(Vt + 4 * VBUF16);    // WavLM: the head's (2T-1)-entry table
+    const int b = blockIdx.z, head = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int D = p.H * HD;
+    const long ld = 3L * D;
+    const float* base = (const float*)p.qkv + (long)b * p.T * ld + head * HD;
+    const int q_g = blockIdx.x * QT + wave * 32 + l31;
+    const int q_c = q_g < p.T ? q_g : p.T - 1;
+
+    // Q fragments (B operand), split once: step st covers dims st*16 .. +15, this half-wave holds 8 of them
+    uint4 qh[4], ql[4];
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+        const float* qp = base + (long)q_c * ld + st * 16 + 8 * half;
+        split8(*(const float4*)qp, *(const float4*)(qp + 4), qh[st], ql[st]);
+    }
+    const float* btab = nullptr;
+    if (p.bias_table) {
+        const float* src = p.bias_table + (long)head * (2 * p.T - 1);
+        for (int i = threadIdx.x; i < 2 * p.T - 1; i += 256) bias_s[i] = src[i];
+        btab = bias_s;  // made visible by the first __syncthreads()
+    }
+    const float gate = (btab && p.gate) ? p.gate[((long)b * p.H + head) * p.T + q_c] : 1.f;
+
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o0[r] = o1[r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int valid = p.valid[b];
+    const int ntiles = (valid + KT16 - 1) / KT16;
+    const int krow = tid >> 3, kc8 = tid & 7;   // K: rows krow and krow+32, 8-dim chunk kc8
+    const int vj = tid & 31, vdg = tid >> 5;    // V: key pair vj, dim group vdg
+    f32x4 kreg[2][2], vreg[2][2];               // fp32 in flight; split when written to LDS
+    auto clampk = [&](int kr) { return kr < p.T ? kr : p.T - 1; };
+    auto f4 = [](const f32x4& v) { return make_float4(v[0], v[1], v[2], v[3]); };
+#define AX3_LOAD(kt_)                                                                                  \
+    {                                                                                                  \
+        const int k0_ = (kt_) * KT16;                                                                  \
+        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                             \
+            const float* kp_ = base + (long)clampk(k0_ + krow + 32 * i_) * ld + D + kc8 * 8;           \
+            kreg[i_][0] = *(const f32x4*)kp_;                                                          \
+            kreg[i_][1] = *(const f32x4*)(kp_ + 4);                                                    \
+            const float* vp_ = base + (long)clampk(k0_ + 2 * vj + i_) * ld + 2 * D + vdg * 8;          \
+            vreg[i_][0] = *(const f32x4*)vp_;                                                          \
+            vreg[i_][1] = *(const f32x4*)(vp_ + 4);                                                    \
+        }                                                                                              \
+    }
+#define AX3_STORE(buf_)                                                                                \
+    {                                                                                                  \
+        uint4 kh_[2], kl_[2], vh_[2], vl_[2];                                                          \
+        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                             \
+            split8(f4(kreg[i_][0]), f4(kreg[i_][1]), kh_[i_], kl_[i_]);                                \
+            split8(f4(vreg[i_][0]), f4(vreg[i_][1]), vh_[i_], vl_[i_]);                                \
+            *(uint4*)(Ks + (0 * 2 + (buf_)) * KBUF16 + (krow + 32 * i_) * KS16 + kc8 * 8) = kh_[i_];   \
+            *(uint4*)(Ks + (1 * 2 + (buf_)) * KBUF16 + (krow + 32 * i_) * KS16 + kc8 * 8) = kl_[i_];   \
+        }                                                                                              \
+        _Pragma("unroll") for (int pl_ = 0; pl_ < 2; ++pl_) {                                          \
+            u16* vt_ = Vt + (pl_ * 2 + (buf_)) * VBUF16;                                               \
+            const unsigned a_[4] = {pl_ ? vl_[0].x : vh_[0].x, pl_ ? vl_[0].y : vh_[0].y, pl_ ? vl_[0].z : vh_[0].z, pl_ ? vl_[0].w : vh_[0].w}; \
+            const unsigned b_[4] = {pl_ ? vl_[1].x : vh_[1].x, pl_ ? vl_[1].y : vh_[1].y, pl_ ? vl_[1].z : vh_[1].z, pl_ ? vl_[1].w : vh_[1].w}; \
+            _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                         \
+                *(unsigned*)(vt_ + (vdg * 8 + 2 * i_) * VS16 + 2 * vj) = (a_[i_] & 0xffffu) | (b_[i_] << 16);          \
+                *(unsigned*)(vt_ + (vdg * 8 + 2 * i_ + 1) * VS16 + 2 * vj) = (a_[i_] >> 16) | (b_[i_] & 0xffff0000u);  \
+            }                                                                                          \
+        }                                                                                              \
+    }
+    AX3_LOAD(0)
+    AX3_STORE(0)
+    __syncthreads();
+
+    for (int kt = 0; kt < ntiles; ++kt) {
+        if (kt + 1 < ntiles) AX3_LOAD(kt + 1)
+        const u16* ksh = Ks + (0 * 2 + (kt & 1)) * KBUF16;
+        const u16* ksl = Ks + (1 * 2 + (kt & 1)) * KBUF16;
+        const u16* vth = Vt + (0 * 2 + (kt & 1)) * VBUF16;
+        const u16* vtl = Vt + (1 * 2 + (kt & 1)) * VBUF16;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int k0 = kt * KT16 + h * 32;
+            if (k0 >= valid) break;  // wave-uniform: the whole half is masked
+            f32x16 sc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const int ko = (h * 32 + l31) * KS16 + st * 16 + 8 * half;
+                const uint4 kh = *(const uint4*)(ksh + ko), kl = *(const uint4*)(ksl + ko);
+                sc = Mma16<bf16_tag>::run(kl, qh[st], sc);
+                sc = Mma16<bf16_tag>::run(kh, ql[st], sc);
+                sc = Mma16<bf16_tag>::run(kh, qh[st], sc);
+            }
+            if (btab) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = k0 + crow(r, half);
+                    if (key < p.T) sc[r] += gate * btab[key - q_c + p.T - 1];
+                }
+            }
+            if (k0 + 32 > valid) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sc[r] = k0 + crow(r, half) < valid ? sc[r] : -INFINITY;
+            }
+            float mx = sc[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sc[r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            if (__any(mx > m_run + 8.f)) {
+                const float m_new = fmaxf(m_run, mx);
+                const float alpha = __expf(m_run - m_new);
+                l_run *= alpha;
+                m_run = m_new;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    o0[r] *= alpha;
+                    o1[r] *= alpha;
+                }
+            }
+            float ps = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                sc[r] = __expf(sc[r] - m_run);
+                ps += sc[r];
+            }
+            l_run += ps;
+            // P^T as B operand, split: step u uses regs 8u..8u+7  <->  keys 32h + 16u + {0,1,2,3,8,9,10,11} + 4*half
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                uint4 ph, pl;
+                split8(make_float4(sc[8 * u], sc[8 * u + 1], sc[8 * u + 2], sc[8 * u + 3]),
+                       make_float4(sc[8 * u + 4], sc[8 * u + 5], sc[8 * u + 6], sc[8 * u + 7]), ph, pl);
+                const int vo = l31 * VS16 + 32 * h + 16 * u + 4 * half;
+                auto frag = [&](const u16* vt, int off) {
+                    const uint2 a0 = *(const uint2*)(vt + off), a1 = *(const uint2*)(vt + off + 8);
+                    return make_uint4(a0.x, a0.y, a1.x, a1.y);
+                };
+                const uint4 vh0 = frag(vth, vo), vl0 = frag(vtl, vo);
+                const uint4 vh1 = frag(vth, vo + 32 * VS16), vl1 = frag(vtl, vo + 32 * VS16);
+                o0 = Mma16<bf16_tag>::run(vl0, ph, o0);
+                o0 = Mma16<bf16_tag>::run(vh0, pl, o0);
+                o0 = Mma16<bf16_tag>::run(vh0, ph, o0);
+                o1 = Mma16<bf16_tag>::run(vl1, ph, o1);
+                o1 = Mma16<bf16_tag>::run(vh1, pl, o1);
+                o1 = Mma16<bf16_tag>::run(vh1, ph, o1);
+            }
+        }
+        if (kt + 1 < ntiles) AX3_STORE((kt + 1) & 1)
+        __syncthreads();
+    }
+#undef AX3_LOAD
+#undef AX3_STORE
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.f / l_tot;
+    if (q_g < p.T) {
+        float* op = (float*)p.out + ((long)b * p.T + q_g) * D + head * HD + 4 * half;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            *(float4*)(op + 8 * g) = make_float4(o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
+            *(float4*)(op + 32 + 8 * g) = make_float4(o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+        }
+    }
+}
+
 // One wavefront per (b, t) row: the D floats are read once as coalesced float4s (16 lanes per head), the four summed
 // grep_linear outputs of each gate half are ONE dot product with the summed weight rows (sum_o (W_o x + b_o) =
 // (sum_o W_o) x + sum_o b_o), reduced over the head's 16 lanes with four shuffles.
@@ -401,6 +574,13 @@ hipError_t launch_attention(int dtype, const AttnParams& p, hipStream_t s) {
         case F32: hipLaunchKernelGGL(attn_f32_kernel, grid, block, dyn, s, p); break;
         case BF16: hipLaunchKernelGGL(attn_h16_kernel<bf16_tag>, grid, block, dyn, s, p); break;
         case F16: hipLaunchKernelGGL(attn_h16_kernel<f16_tag>, grid, block, dyn, s, p); break;
+        case 3: {  // S3ENC_F32X3: fp32 q|k|v and output, split-precision products; all of its LDS is dynamic
+            const size_t lds = (size_t)(4 * KBUF16 + 4 * VBUF16) * sizeof(u16) + dyn;
+            hipError_t e = ensure_dynamic_lds<attn_x3_kernel>((int)lds);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(attn_x3_kernel, grid, block, lds, s, p);
+            break;
+        }
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

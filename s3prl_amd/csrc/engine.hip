@@ -864,7 +864,7 @@ int forward_impl(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
             a.bias_table = d_table;
             a.gate = gated ? (const float*)gate : nullptr;
             Prof pr(e, st, "attention", 4.0 * B * H * (double)T * T * 64, gM * 4 * D * es);
-            HIP_TRY(launch_attention(dt, a, st));
+            HIP_TRY(launch_attention(e->x3 ? 3 : dt, a, st));
             if (l == 0) e->taps["attn0"] = {attn, M * D, dt};
         }
         {   // out_proj + bias + residual

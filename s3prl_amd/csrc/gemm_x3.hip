@@ -7,9 +7,9 @@
 // and the product is rebuilt from three bf16 MFMAs with fp32 accumulation,
 //     a*w  ~=  a_hi*w_hi + a_lo*w_hi + a_hi*w_lo          (dropped: a_lo*w_lo ~ 2^-18, truncation r ~ 2^-17)
 // i.e. a relative error of ~1e-5 per product (random sign) at 3/16 of the fp32 MFMA cost.  No range is lost (bf16 has
-// the fp32 exponent).  It is an OPT-IN mode (compute_dtype S3ENC_F32X3): activations, residual stream, norms, softmax
-// and attention stay exactly as in the fp32 mode — only the GEMMs (here) and the positional conv (posconv.hip, same
-// split) change.
+// the fp32 exponent).  It is an OPT-IN mode (compute_dtype S3ENC_F32X3): activations, residual stream, norms and the
+// softmax stay exactly as in the fp32 mode — only the matrix products change: the GEMMs (here), the positional conv
+// (posconv.hip) and the two products of the attention (attention.hip: attn_x3_kernel), all with the same split.
 //   * A (activations) stays fp32 in memory and in LDS; the split happens on the fragment registers
 //     (v_cvt_pk_bf16_f32 + 2 v_sub + a shift / mask per pair: ~100 VALU per 24 MFMAs, hidden beside them).
 //   * W is split once at pack time into a "pair-packed" image with the same bytes and the same addressing as fp32:

@@ -202,7 +202,7 @@ def _attention_ref(qkv, valid, B, T, H, table=None, gate=None):
     return (p @ v).transpose(0, 2, 1, 3).reshape(B * T, D)
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16", "fp32x3"])
 @pytest.mark.parametrize("T,rel", [(33, False), (200, False), (149, True), (499, False)])
 def test_attention(dtype, T, rel):
     torch = _torch()
@@ -236,7 +236,7 @@ def test_attention(dtype, T, rel):
     got = out.float().cpu().numpy()
     assert np.isfinite(got).all()
     err = O.rel_err(got, ref)
-    assert err < {"fp32": 2e-5, "bf16": 1.5e-2, "fp16": 2e-3}[dtype], f"attention {dtype} T={T}: rel-err {err:.3e}"
+    assert err < {"fp32": 2e-5, "bf16": 1.5e-2, "fp16": 2e-3, "fp32x3": 5e-5}[dtype], f"attention {dtype} T={T}: rel-err {err:.3e}"
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16", "fp32x3"])
