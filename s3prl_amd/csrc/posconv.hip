@@ -143,8 +143,7 @@ template <> struct Mma16x16<f16_tag> {
 
 // X3: split-precision variant of the fp32x3 mode (S3ENC_F32X3): the fp32 window is split into a bf16 hi and a bf16 lo
 // plane, W arrives as a hi and a lo image ([G][Dg][K*Dg] each, lo after hi), every product is
-// a_hi*w_hi + a_lo*w_hi + a_hi*w_lo (~1e-5 relative, see gemm_x3.hip); 128 frames per workgroup (two planes of LDS),
-// libm erff GELU like the fp32 kernel.
+// a_hi*w_hi + a_lo*w_hi + a_hi*w_lo (~1e-5 relative, see gemm_x3.hip); 128 frames per workgroup (two planes of LDS).
 template <typename T, int DG, bool X3>
 __global__ __launch_bounds__(256) void posconv16_kernel(PosConvParams p) {
     constexpr int NT = DG / 16;  // 16-wide output-channel tiles
@@ -264,7 +263,7 @@ __global__ __launch_bounds__(256) void posconv16_kernel(PosConvParams p) {
                 if (t < p.T) {
                     const long o = ((long)b * p.T + t) * p.D + c;
                     const float y = acc[m][n][r] + bias;
-                    p.out[o] = p.x[o] + (X3 ? gelu_erf(y) : gelu_fast(y));
+                    p.out[o] = p.x[o] + gelu_fast(y);
                 }
             }
     }
