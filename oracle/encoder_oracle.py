@@ -208,8 +208,9 @@ def multihead_attention(cfg, W, prefix: str, x: np.ndarray, valid: Sequence[int]
 # transformer layer + encoder
 # ------------------------------------------------------------------------------------------------
 
-def encoder_layer(cfg, W, l: int, x: np.ndarray, valid, pos_bias) -> np.ndarray:
-    """``TransformerSentenceEncoderLayer.forward`` (wav2vec2_model.py:3260-3322; WavLM.py:709-774)."""
+def encoder_layer(cfg, W, l: int, x: np.ndarray, valid, pos_bias, ffn_out: Optional[list] = None) -> np.ndarray:
+    """``TransformerSentenceEncoderLayer.forward`` (wav2vec2_model.py:3260-3322; WavLM.py:709-774;
+    distiller/module.py:191-243).  ``ffn_out`` collects ``layer_result`` = fc2 output before the residual (:3296,3317)."""
     p = f"encoder.layers.{l}"
     dt = x.dtype
     ln1 = (W[f"{p}.self_attn_layer_norm.weight"].astype(dt), W[f"{p}.self_attn_layer_norm.bias"].astype(dt))
@@ -217,7 +218,10 @@ def encoder_layer(cfg, W, l: int, x: np.ndarray, valid, pos_bias) -> np.ndarray:
 
     def ffn(h):
         h = gelu(h @ W[f"{p}.fc1.weight"].T.astype(dt) + W[f"{p}.fc1.bias"].astype(dt))
-        return h @ W[f"{p}.fc2.weight"].T.astype(dt) + W[f"{p}.fc2.bias"].astype(dt)
+        h = h @ W[f"{p}.fc2.weight"].T.astype(dt) + W[f"{p}.fc2.bias"].astype(dt)
+        if ffn_out is not None:
+            ffn_out.append(h.astype(dt))
+        return h
 
     if cfg.layer_norm_first:
         x = x + multihead_attention(cfg, W, f"{p}.self_attn", layer_norm(x, *ln1), valid, pos_bias)
@@ -229,13 +233,17 @@ def encoder_layer(cfg, W, l: int, x: np.ndarray, valid, pos_bias) -> np.ndarray:
 
 
 def forward(cfg, weights: Dict[str, np.ndarray], wavs: List[np.ndarray], dtype=np.float32,
-            n_max: Optional[int] = None, taps: Optional[dict] = None) -> List[np.ndarray]:
-    """``UpstreamExpert.__call__(wavs)["hidden_states"]`` for hubert / wav2vec2 / wavlm.
+            n_max: Optional[int] = None, taps: Optional[dict] = None, selection: Optional[str] = None) -> List[np.ndarray]:
+    """``UpstreamExpert.__call__(wavs)["hidden_states"]`` for hubert / wav2vec2 / wavlm / distiller.
 
     Follows hubert/expert.py:56-72 → HubertModel.forward (hubert_model.py:466-513) →
     TransformerEncoder (wav2vec2_model.py:3046-3121); the hook capture of upstream/interfaces.py:90-131
     becomes the returned list: [input of layer 0 .. input of layer NL-1, encoder output].
     ``n_max`` > max(len) reproduces a data-parallel shard padded to the global batch maximum (§8e).
+    ``selection`` (wav2vec2/expert.py:81-93): "fairseq_layers" = every layer's output (``layer_results[i][0]``),
+    "fairseq_layers_before_residual" = every layer's fc2 output before the residual (``layer_results[i][2]``).
+    family "distiller" (distiller/expert.py:43-52, model.py:178-268, module.py:302-334):
+    [feat_final, layer outputs ..., prediction heads ...].
     """
     dt = np.dtype(dtype)
     W = {k: v.astype(dt) for k, v in weights.items()}
@@ -255,12 +263,15 @@ def forward(cfg, weights: Dict[str, np.ndarray], wavs: List[np.ndarray], dtype=n
     assert T == cfg.num_frames(n_max)
     valid = [cfg.valid_frames(n, n_max) for n in lens]
 
-    x = layer_norm(feats, W["layer_norm.weight"], W["layer_norm.bias"])  # hubert_model.py:482-483
+    x = feats
+    if cfg.feature_layer_norm:
+        x = layer_norm(x, W["layer_norm.weight"], W["layer_norm.bias"])  # hubert_model.py:482-483
     x = x @ W["post_extract_proj.weight"].T + W["post_extract_proj.bias"]  # :489-490
     for b in range(B):
-        x[b, valid[b]:] = 0  # index_put(x, padding_mask, 0) wav2vec2_model.py:3061-3062
+        x[b, valid[b]:] = 0  # index_put(x, padding_mask, 0) wav2vec2_model.py:3061-3062; distiller/module.py:303-304
     if taps is not None:
         taps["proj"] = x.copy()
+    feat_final = x  # distiller: the in-place zeroing above is visible in hidden_states[0] (a view of feat_final)
     x = x + pos_conv(cfg, W, x)  # :3064-3067
     if not cfg.layer_norm_first:
         x = layer_norm(x, W["encoder.layer_norm.weight"], W["encoder.layer_norm.bias"])  # :3069-3070
@@ -269,13 +280,27 @@ def forward(cfg, weights: Dict[str, np.ndarray], wavs: List[np.ndarray], dtype=n
     if cfg.family == "wavlm" and cfg.relative_position_embedding:
         pos_bias = rel_pos_bias(cfg, W, T, dt)  # layer 0 computes it, later layers reuse it (WavLM.py:622-632)
 
-    hidden = []
+    hidden, layer_out, ffn_out = [], [], []
     for l in range(cfg.encoder_layers):
         hidden.append(x)
-        x = encoder_layer(cfg, W, l, x, valid, pos_bias)
+        x = encoder_layer(cfg, W, l, x, valid, pos_bias, ffn_out)
+        layer_out.append(x)
     if cfg.layer_norm_first:
         x = layer_norm(x, W["encoder.layer_norm.weight"], W["encoder.layer_norm.bias"])  # :3049-3050
     hidden.append(x)
+    if selection == "fairseq_layers":
+        return layer_out
+    if selection == "fairseq_layers_before_residual":
+        return ffn_out
+    assert selection is None, selection
+    if cfg.family == "distiller":
+        # output_layer = Linear(D, N*D) -> GELU -> SplitLinear(D, N, D) on the encoder output (model.py:155-161,245;
+        # module.py:77-90); pred.reshape(B, T, N, D).permute(0, 2, 1, 3) -> N tensors (expert.py:47-50)
+        N, D = cfg.pred_heads, cfg.encoder_embed_dim
+        h = gelu(x @ W["output_layer.0.weight"].T + W["output_layer.0.bias"]).reshape(B, T, N, D)
+        w2, b2 = W["output_layer.2.weight"], W["output_layer.2.bias"].reshape(N, D)
+        preds = [(h[:, :, k] @ w2[k] + b2[k]).astype(dt) for k in range(N)]
+        return [feat_final] + layer_out + preds
     return hidden
 
 

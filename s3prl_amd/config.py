@@ -16,7 +16,7 @@ import ast
 from dataclasses import dataclass, field, asdict
 from typing import Dict, List, Tuple
 
-FAMILIES = ("hubert", "wav2vec2", "wavlm")
+FAMILIES = ("hubert", "wav2vec2", "wavlm", "distiller")
 
 # reference default: "[(512,10,5)] + [(512,3,2)] * 4 + [(512,2,2)] * 2"
 DEFAULT_CONV_LAYERS = "[(512,10,5)] + [(512,3,2)] * 4 + [(512,2,2)] * 2"
@@ -75,6 +75,10 @@ class EncoderConfig:
     num_buckets: int = 320
     max_distance: int = 1280
     gru_rel_pos: bool = False
+    # DistilHuBERT (family "distiller", upstream/distiller/model.py:17-80): no LayerNorm between the conv stack and
+    # post_extract_proj, and ``pred_heads`` prediction heads (Linear -> GELU -> SplitLinear) on the last layer
+    feature_layer_norm: bool = True
+    pred_heads: int = 0
 
     # ---- derived -------------------------------------------------------------------------
     @property
@@ -84,6 +88,12 @@ class EncoderConfig:
     @property
     def head_dim(self) -> int:
         return self.encoder_embed_dim // self.encoder_attention_heads
+
+    @property
+    def num_hidden_states(self) -> int:
+        """Entries of the default ``hidden_states`` list: layer inputs + encoder output; DistilHuBERT:
+        feat_final + every layer output + the prediction heads (distiller/expert.py:43-52)."""
+        return self.encoder_layers + 1 + self.pred_heads
 
     @property
     def downsample_rate(self) -> int:
@@ -114,7 +124,7 @@ class EncoderConfig:
         T = self.num_frames(n_max)
         if T <= 0:
             return 0
-        if self.family == "wav2vec2":
+        if self.family in ("wav2vec2", "distiller"):  # distiller: cal_pad_mask, distiller/model.py:271-285
             return min(T, max(self.num_frames(length), 0))
         chunk = n_max // T
         return min(T, -(-length // chunk))
@@ -168,5 +178,33 @@ def config_from_dicts(family: str, model_cfg: Dict, task_cfg: Dict | None = None
     else:
         if task_cfg is not None and "normalize" in task_cfg:
             cfg.normalize = bool(task_cfg["normalize"])
+    cfg.validate()
+    return cfg
+
+
+def config_from_distiller(d: Dict) -> EncoderConfig:
+    """``DistillerConfig`` (upstream/distiller/model.py:17-80) from ``ckpt["Config"]["distiller"]``."""
+    cfg = EncoderConfig(family="distiller", feature_layer_norm=False)
+    cfg.extractor_mode = str(d.get("extractor_mode", "default"))
+    cfg.conv_layers = parse_conv_layers(d.get("extractor_conv_feature_layers", DEFAULT_CONV_LAYERS))
+    cfg.conv_pos = int(d.get("conv_pos", 128))
+    cfg.conv_pos_groups = int(d.get("conv_pos_groups", 16))
+    cfg.encoder_layers = int(d.get("encoder_layers", 1))
+    cfg.encoder_embed_dim = int(d.get("encoder_embed_dim", 768))
+    cfg.encoder_ffn_embed_dim = int(d.get("encoder_ffn_embed_dim", 3072))
+    cfg.encoder_attention_heads = int(d.get("encoder_attention_heads", 12))
+    cfg.layer_norm_first = bool(d.get("layer_norm_first", False))
+    if str(d.get("activation_fn", "gelu")) != "gelu":
+        raise ValueError("only activation_fn='gelu' is on the hot path")
+    if str(d.get("attention_type", "original")) != "original":
+        raise ValueError("distiller attention_type must be 'original'")
+    task, out = str(d.get("task_emb_type", "expand-last")), str(d.get("out_layer_type", "expand-last"))
+    if task != "expand-last" or out != "expand-last":
+        raise ValueError("only the DistilHuBERT head layout (task_emb_type = out_layer_type = 'expand-last') is built")
+    cfg.pred_heads = int(d.get("n_tasks", 12))
+    if int(d.get("final_dim", 768)) != cfg.encoder_embed_dim or int(d.get("out_layer_inter_dim", -1)) > 0:
+        raise ValueError("distiller heads must keep the encoder width (final_dim == encoder_embed_dim, no inter dim)")
+    if cfg.conv_dim == cfg.encoder_embed_dim:
+        raise ValueError("distiller without post_extract_proj (conv width == encoder width) is not built")
     cfg.validate()
     return cfg

@@ -35,8 +35,9 @@ def param_shapes(cfg: EncoderConfig) -> Dict[str, tuple]:
             s[f"{p}.2.bias"] = (dim,)
         cin = dim
     C, D, F, H = cfg.conv_dim, cfg.encoder_embed_dim, cfg.encoder_ffn_embed_dim, cfg.encoder_attention_heads
-    s["layer_norm.weight"] = (C,)
-    s["layer_norm.bias"] = (C,)
+    if cfg.feature_layer_norm:
+        s["layer_norm.weight"] = (C,)
+        s["layer_norm.bias"] = (C,)
     s["post_extract_proj.weight"] = (D, C)
     s["post_extract_proj.bias"] = (D,)
     s["encoder.pos_conv.0.bias"] = (D,)
@@ -64,6 +65,12 @@ def param_shapes(cfg: EncoderConfig) -> Dict[str, tuple]:
                 s[f"{p}.self_attn.grep_linear.weight"] = (8, cfg.head_dim)
                 s[f"{p}.self_attn.grep_linear.bias"] = (8,)
                 s[f"{p}.self_attn.grep_a"] = (1, H, 1, 1)
+    if cfg.pred_heads:  # distiller/model.py:155-161: Linear(D, D*N) -> GELU -> SplitLinear(D, N, D)
+        N = cfg.pred_heads
+        s["output_layer.0.weight"] = (D * N, D)
+        s["output_layer.0.bias"] = (D * N,)
+        s["output_layer.2.weight"] = (N, D, D)
+        s["output_layer.2.bias"] = (1, 1, N, D)
     return s
 
 
@@ -81,6 +88,8 @@ def synth_weights(cfg: EncoderConfig, seed: int = 0) -> Dict[str, np.ndarray]:
             # weight_norm gain: w[:,:,k] = g[k] * v[:,:,k] / ||v[:,:,k]||  → RMS(w) = g/sqrt(numel per tap)
             d_out, d_in, _ = param_shapes(cfg)["encoder.pos_conv.0.weight_v"]
             w = (1.0 + 0.2 * rng.standard_normal(shape)) * np.sqrt(d_out / shape[-1]) * 0.5
+        elif name == "output_layer.2.weight":  # SplitLinear (N, Din, Dout)
+            w = rng.standard_normal(shape) * np.sqrt(1.0 / shape[1])
         elif leaf == "weight" and len(shape) == 1:  # norm gains
             w = 1.0 + 0.1 * rng.standard_normal(shape)
         elif leaf == "bias":
@@ -139,6 +148,9 @@ def named_config(name: str) -> EncoderConfig:
         "wav2vec2_large": dict(family="wav2vec2", conv_bias=True, **large),
         "wavlm_large": dict(family="wavlm", conv_bias=False, relative_position_embedding=True,
                             num_buckets=320, max_distance=800, gru_rel_pos=True, **large),
+        "distilhubert": dict(family="distiller", encoder_layers=2, feature_layer_norm=False, pred_heads=3),
+        "tiny_distiller": dict(family="distiller", feature_layer_norm=False, pred_heads=3, **{**tiny, "encoder_layers": 2}),
+        "tiny_wavlm_norel": dict(family="wavlm", **tiny),
         "tiny_hubert": dict(family="hubert", **tiny),
         "tiny_wav2vec2": dict(family="wav2vec2", **tiny),
         "tiny_hubert_large": dict(family="hubert", **{**tiny, "extractor_mode": "layer_norm",

@@ -16,8 +16,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
 
 
-def golden_names():
-    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz"))
+def golden_names(encoder_only=True):
+    """Encoder fixtures (hidden_states of a reference expert); ``feat_*`` fixtures pin the Featurizer / S3PRLUpstream."""
+    names = sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz"))
+    return [n for n in names if not n.startswith("feat_")] if encoder_only else names
+
+
+def golden_meta(name):
+    z = np.load(os.path.join(GOLDEN_DIR, f"{name}.npz"))
+    return json.loads(bytes(z["meta"]).decode())
 
 
 def load_golden(name):
@@ -29,7 +36,7 @@ def load_golden(name):
     cfg = named_config(meta["config"])
     weights = synth_weights(cfg, meta["weight_seed"])
     wavs = synth_wavs(meta["lengths"], meta["wav_seed"], dc=meta["dc"], scale=meta["scale"])
-    hs = [z[f"hs{l}"] for l in range(cfg.encoder_layers + 1)]
+    hs = [z[f"hs{l}"] for l in range(meta.get("n_states", cfg.encoder_layers + 1))]
     return meta, cfg, weights, wavs, hs, z["norms"]
 
 

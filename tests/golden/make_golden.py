@@ -49,21 +49,43 @@ CASES = {
     "wavlm_base_plus_pseudo": ("wavlm_base_plus", 0, 23, [23456, 16000], (4, 8), 0.0, 1.0),
     "hubert_large_pseudo": ("hubert_large", 0, 24, [16000, 12000], (4, 16), 0.0, 1.0),
     "wavlm_large_pseudo": ("wavlm_large", 0, 25, [16000, 12000], (4, 16), 0.0, 1.0),
+    # full-size shapes of BASELINE configs[3] / [4] (round 2): T = 499 / 749, D = 1024, H = 16, Dg = 64
+    "hubert_large_10s": ("hubert_large", 0, 26, [160000, 160000], (8, 32), 0.0, 1.0),
+    "wavlm_large_15s_pad": ("wavlm_large", 0, 27, [240000, 61234], (8, 32), 0.0, 1.0),
+    # SURVEY §8f-3 siblings
+    "tiny_wavlm_norel_pad": ("tiny_wavlm_norel", 9, 19, [4000, 2345, 3111], (1, 1), 0.0, 1.0),
+    "wavlm_base_norel_pseudo": ("wavlm_base", 0, 28, [20000, 27123], (4, 8), 0.0, 1.0),
+    "tiny_unispeech_sat_pad": ("tiny_wavlm", 10, 20, [4000, 2345, 3111], (1, 1), 0.0, 1.0, {"expert": "unispeech_sat"}),
+    "unispeech_sat_base_pseudo": ("wavlm_base", 1, 29, [23456, 16000], (4, 8), 0.0, 1.0, {"expert": "unispeech_sat"}),
+    "tiny_distiller_pad": ("tiny_distiller", 11, 30, [4000, 2345, 3111, 800], (1, 1), 0.0, 1.0),
+    "distilhubert_pseudo": ("distilhubert", 0, 31, [23456, 16000], (4, 8), 0.0, 1.0),
+    # wav2vec2 feature_selection (wav2vec2/expert.py:81-93)
+    "tiny_wav2vec2_fslayers": ("tiny_wav2vec2", 3, 13, [4000, 2345, 3111, 800], (1, 1), 0.0, 1.0,
+                               {"selection": "fairseq_layers"}),
+    "tiny_wav2vec2_fsbefore": ("tiny_wav2vec2", 3, 13, [4000, 2345, 3111, 800], (1, 1), 0.0, 1.0,
+                               {"selection": "fairseq_layers_before_residual"}),
+    "tiny_wav2vec2_large_fslayers": ("tiny_wav2vec2_large", 6, 16, [3500, 4000, 1700], (1, 1), 0.0, 1.0,
+                                     {"selection": "fairseq_layers"}),
+    "tiny_wav2vec2_large_fsbefore": ("tiny_wav2vec2_large", 6, 16, [3500, 4000, 1700], (1, 1), 0.0, 1.0,
+                                     {"selection": "fairseq_layers_before_residual"}),
 }
 
 
 def _import_reference():
     import torch  # noqa: F401
 
-    # s3prl/util/pseudo_data.py:15 imports torchaudio at module level; shim it.
-    sys.modules.setdefault("torchaudio", types.ModuleType("torchaudio"))
-    if REFERENCE not in sys.path:
-        sys.path.insert(0, REFERENCE)
+    # s3prl/util/pseudo_data.py:15 imports torchaudio at module level; placeholder modules stand in.
+    sys.path.insert(0, HERE)
+    import ref_shim
+
+    ref_shim.import_reference()
 
 
-def build_reference_expert(cfg, weights, tmpdir):
+def build_reference_expert(cfg, weights, tmpdir, extras=None):
     """Instantiate the reference model for ``cfg``, load ``weights`` and return its UpstreamExpert."""
     import torch
+
+    extras = extras or {}
 
     _import_reference()
     conv_str = str([tuple(t) for t in cfg.conv_layers])
@@ -95,16 +117,34 @@ def build_reference_expert(cfg, weights, tmpdir):
         _load(model, weights)
         torch.save({"task_cfg": dataclasses.asdict(tc), "model_cfg": dataclasses.asdict(mc),
                     "model_weight": model.state_dict()}, path)
+    elif cfg.family == "distiller":
+        from s3prl.upstream.distiller.expert import UpstreamExpert
+        from s3prl.upstream.distiller.model import DistillerConfig, DistillerModel
+
+        d = dict(extractor_mode=cfg.extractor_mode, extractor_conv_feature_layers=conv_str, conv_pos=cfg.conv_pos,
+                 conv_pos_groups=cfg.conv_pos_groups, encoder_layers=cfg.encoder_layers,
+                 encoder_embed_dim=cfg.encoder_embed_dim, encoder_ffn_embed_dim=cfg.encoder_ffn_embed_dim,
+                 encoder_attention_heads=cfg.encoder_attention_heads, layer_norm_first=cfg.layer_norm_first,
+                 final_dim=cfg.encoder_embed_dim, n_tasks=cfg.pred_heads,
+                 pred_layer_id=[4 * (i + 1) for i in range(cfg.pred_heads)], task_emb_type="expand-last",
+                 out_layer_type="expand-last")
+        model = DistillerModel(DistillerConfig(d))
+        _load(model, weights)
+        torch.save({"Config": {"distiller": d}, "Distiller": model.state_dict()}, path)
     else:
         from s3prl.upstream.wavlm.WavLM import WavLM, WavLMConfig
-        from s3prl.upstream.wavlm.expert import UpstreamExpert
+        if extras.get("expert") == "unispeech_sat":
+            from s3prl.upstream.unispeech_sat.expert import UpstreamExpert
+        else:
+            from s3prl.upstream.wavlm.expert import UpstreamExpert
 
         d = dict(common, normalize=cfg.normalize, relative_position_embedding=cfg.relative_position_embedding,
                  num_buckets=cfg.num_buckets, max_distance=cfg.max_distance, gru_rel_pos=cfg.gru_rel_pos)
         model = WavLM(WavLMConfig(d))
         _load(model, weights)
         torch.save({"cfg": d, "model": model.state_dict()}, path)
-    expert = UpstreamExpert(path).eval()
+    kw = {"feature_selection": extras["selection"]} if extras.get("selection") else {}
+    expert = UpstreamExpert(path, **kw).eval()
     return expert, path
 
 
@@ -120,25 +160,27 @@ def _load(model, weights):
     model.load_state_dict(sd)
 
 
-def reference_hidden_states(cfg, weights, wavs):
+def reference_hidden_states(cfg, weights, wavs, extras=None):
     import torch
 
     with tempfile.TemporaryDirectory() as tmp:
-        expert, _ = build_reference_expert(cfg, weights, tmp)
+        expert, _ = build_reference_expert(cfg, weights, tmp, extras)
         with torch.no_grad():
             out = expert([torch.from_numpy(w.copy()) for w in wavs])
     return [h.numpy() for h in out["hidden_states"]], out
 
 
 def make_case(name: str):
-    cfg_name, wseed, xseed, lengths, (ts, cs), dc, scale = CASES[name]
+    cfg_name, wseed, xseed, lengths, (ts, cs), dc, scale = CASES[name][:7]
+    extras = CASES[name][7] if len(CASES[name]) > 7 else {}
     cfg = named_config(cfg_name)
     weights = synth_weights(cfg, wseed)
     wavs = synth_wavs(lengths, xseed, dc=dc, scale=scale)
-    hs, out = reference_hidden_states(cfg, weights, wavs)
-    assert len(hs) == cfg.encoder_layers + 1
+    hs, out = reference_hidden_states(cfg, weights, wavs, extras)
+    assert len(hs) == (cfg.encoder_layers if extras.get("selection") else cfg.num_hidden_states)
     meta = dict(config=cfg_name, weight_seed=wseed, wav_seed=xseed, lengths=lengths, t_stride=ts, c_stride=cs,
-                dc=dc, scale=scale, shape=list(hs[0].shape), reference="s3prl 0.4.18 @ /root/reference, torch CPU fp32")
+                dc=dc, scale=scale, shape=list(hs[0].shape), reference="s3prl 0.4.18 @ /root/reference, torch CPU fp32",
+                n_states=len(hs), **extras)
     arrays = {f"hs{l}": np.ascontiguousarray(h[:, ::ts, ::cs]) for l, h in enumerate(hs)}
     # full-tensor norms so a subsampled fixture still pins the global scale of every layer
     arrays["norms"] = np.array([np.linalg.norm(h.astype(np.float64)) for h in hs])
