@@ -24,12 +24,15 @@
 extern "C" {
 #endif
 
-#define S3ENC_VERSION 1
+#define S3ENC_VERSION 2
 #define S3ENC_MAX_CONV 16
 
 typedef struct s3enc_encoder* s3enc_handle;
 
-enum { S3ENC_HUBERT = 0, S3ENC_WAV2VEC2 = 1, S3ENC_WAVLM = 2 };
+enum { S3ENC_HUBERT = 0, S3ENC_WAV2VEC2 = 1, S3ENC_WAVLM = 2,
+       /* DistilHuBERT (upstream/distiller/model.py:83-268): HuBERT-style encoder without the LayerNorm before
+        * post_extract_proj, wav2vec2's conv-length frame mask, prediction heads on the last layer */
+       S3ENC_DISTILLER = 3 };
 /* arithmetic type of the GEMM / attention operands; accumulation, norms, softmax, GELU and the residual
  * stream are always fp32 (the reference's Fp32GroupNorm / Fp32LayerNorm / fp32 softmax guards,
  * wav2vec2_model.py:1826-1853,1899-1900). */
@@ -63,7 +66,10 @@ typedef struct s3enc_config {
     int32_t num_buckets;
     int32_t max_distance;
     int32_t gru_rel_pos;
-    int32_t compute_dtype;                 /* S3ENC_F32 / BF16 / F16 */
+    int32_t compute_dtype;                 /* S3ENC_F32 / BF16 / F16 / F32X3 */
+    int32_t no_feature_layer_norm;         /* 1: post_extract_proj reads the conv output directly (distiller/model.py:170-176) */
+    int32_t pred_heads;                    /* DistilHuBERT: N prediction heads Linear(D, N*D) -> GELU -> SplitLinear(D, N, D)
+                                            * (distiller/model.py:155-161, module.py:55-90); 0 otherwise */
 } s3enc_config;
 
 /* A named fp32 host tensor of the checkpoint, named exactly like the reference state_dict entry
@@ -106,6 +112,30 @@ int s3enc_valid_frames(s3enc_handle h, int64_t length, int64_t n_max, int32_t* v
  */
 int s3enc_forward(s3enc_handle h, const float* const* wavs, const int64_t* lengths, int32_t B, int64_t n_max,
                   float* out, int64_t layer_stride, void* stream);
+
+/* Which tensors of the forward are "the states", and how they leave the library.
+ * Replaces: the hook selection of the experts (hubert/expert.py:36-43: layer inputs + encoder output), wav2vec2's
+ * feature_selection (wav2vec2/expert.py:81-93: layer_results[i][0] / [i][2]), the DistilHuBERT list
+ * (distiller/expert.py:43-52), and — with `featurize` — Featurizer._weighted_sum applied as the encoder's epilogue
+ * (nn/upstream.py:312-328, upstream/interfaces.py:221-249). */
+enum { S3ENC_SEL_HIDDEN = 0,     /* default list: encoder_layers+1 states (DistilHuBERT: 1 + layers + pred_heads) */
+       S3ENC_SEL_LAYER_OUT = 1,  /* "fairseq_layers": every layer's output (encoder_layers states) */
+       S3ENC_SEL_FFN_OUT = 2 };  /* "fairseq_layers_before_residual": every layer's fc2 output before the residual */
+typedef struct s3enc_forward_opts {
+    int32_t selection;       /* S3ENC_SEL_* */
+    int32_t out_dtype;       /* S3ENC_F32, or the handle's own 16-bit compute dtype: states are then written as 16-bit
+                              * values (half the slab bytes and half the data-parallel all-gather); ignored with featurize */
+    int32_t featurize;       /* 1: write ONLY  out[b][t][:] = sum_i feat_w[i] * (feat_normalize ? layer_norm(state_i) : state_i)
+                              * as one fp32 (B, T, D) block — the states themselves never leave the workspace */
+    int32_t feat_normalize;  /* F.layer_norm(state, (D,)) (no affine, eps 1e-5) before the sum */
+    const float* feat_w;     /* host, one weight per state of the selection (softmax already applied; 0 = unselected) */
+} s3enc_forward_opts;
+/* number of states of a selection (the leading extent of `out` when not featurizing) */
+int s3enc_num_states(s3enc_handle h, int32_t selection, int32_t* n);
+/* s3enc_forward with options; opts == NULL is s3enc_forward.  out: device; state i is the contiguous (B, T, D) block at
+ * out + i*layer_stride ELEMENTS of out_dtype (featurize: one fp32 (B, T, D) block, layer_stride ignored). */
+int s3enc_forward_ex(s3enc_handle h, const float* const* wavs, const int64_t* lengths, int32_t B, int64_t n_max,
+                     const s3enc_forward_opts* opts, void* out, int64_t layer_stride, void* stream);
 
 /* Optional: `n` = encoder_layers+1 hipEvent_t handles (as void*); the following forwards record events[l] on the
  * launch stream as soon as hidden_states[l] is final, so a communication stream can start the all-gather of layer l
@@ -157,14 +187,30 @@ int s3enc_op_gemm(int32_t dtype, const void* A, int64_t lda, int64_t a_batch_str
                   const float* residual, const int32_t* row_limit, float* out32, void* out16, int64_t ldo,
                   int64_t o_batch_stride, void* stream);
 
+/* conv0 of the feature extractor with its normalisation and GELU (wav2vec2_model.py:2879-2906) on raw waveforms:
+ * per-utterance waveform layer-norm if `normalize`; GroupNorm(C, C) over all L0 frames incl. the zero padding when
+ * gn_gamma != NULL (statistics from the waveform's lag sums), else LayerNorm(C) per frame when ln_gamma != NULL.
+ * wavs / lengths as in s3enc_forward; w0 (C, 10), bias (C or NULL), gamma / beta: device fp32; out: device
+ * (B, L0, C) of `dtype`, L0 = (n_max - 10) / stride + 1. */
+int s3enc_op_conv0(int32_t dtype, const float* const* wavs, const int64_t* lengths, int32_t B, int64_t n_max,
+                   int32_t normalize, const float* w0, const float* bias, const float* gn_gamma, const float* gn_beta,
+                   const float* ln_gamma, const float* ln_beta, int32_t C, int32_t stride, void* out, void* stream);
+/* WavLM gate (wavlm/modules.py:535-549) from the attention input x (device fp32 (B, T, H*64)):
+ * gate[b][h][t] = a * (b * grep_a[h] - 1) + 2,  a|b = sigmoid(sum4(grep_linear(x_head))).  grep_w (8, 64), grep_b (8),
+ * grep_a (H): device fp32. */
+int s3enc_op_wavlm_gate(const float* x, const float* grep_w, const float* grep_b, const float* grep_a, int32_t B, int32_t T,
+                        int32_t H, float* gate, void* stream);
+
 /* Row LayerNorm over C (eps 1e-5, biased variance), optional erf-GELU, fp32 in, fp32 and/or dtype out. */
 int s3enc_op_layernorm(int32_t dtype, const float* x, const float* gamma, const float* beta, int32_t rows,
                        int32_t C, int32_t act, float* out32, void* out16, void* stream);
 
 /* Multi-head self-attention on a fused (B*T, 3D) q|k|v buffer (q pre-scaled), head_dim 64, keys >= valid[b]
- * masked; optional WavLM gated relative-position bias: score += gate[b][h][i] * table[h][(j-i)+(T-1)]. */
+ * masked; optional WavLM gated relative-position bias: score += gate[b][h][i] * table[h][clamp(j-i, -R, R) + R]
+ * with a (H, 2R+1) table (the bucket of wavlm/modules.py:418-446 is constant for |j-i| >= max_distance, so
+ * R = max_distance serves every T). */
 int s3enc_op_attention(int32_t dtype, const void* qkv, void* out, const int32_t* valid, int32_t B, int32_t T,
-                       int32_t H, const float* bias_table, const float* gate, void* stream);
+                       int32_t H, const float* bias_table, int32_t table_R, const float* gate, void* stream);
 
 /* Convolutional position embedding + residual: out = x + GELU(SamePad(Conv1d(D, D, K, padding=K/2, groups=G)(x)) + bias)
  * (make_conv_pos / SamePad, wav2vec2_model.py:2937-2953,1797-1808).  x, out: device fp32 (B, T, D); w_host: HOST fp32
@@ -180,9 +226,11 @@ int s3enc_op_posconv(int32_t dtype, const float* x, const float* w_host, const f
 int s3enc_weighted_sum(const float* hs, int64_t layer_stride, int32_t L, const float* w, int32_t normalize, int64_t rows,
                        int32_t D, float* out, void* stream);
 /* Gradient of the above w.r.t. w (the upstream is frozen): grad_w[l] = sum <grad_out, hn_l>; grad_w: device, L floats.
- * Synchronises (scratch is freed on return). */
+ * scratch: device, s3enc_weighted_sum_backward_scratch(rows, L) doubles, owned by the caller (stream-ordered reuse);
+ * asynchronous on `stream`. */
+int64_t s3enc_weighted_sum_backward_scratch(int64_t rows, int32_t L);
 int s3enc_weighted_sum_backward(const float* hs, int64_t layer_stride, int32_t L, int32_t normalize, int64_t rows,
-                                int32_t D, const float* grad_out, float* grad_w, void* stream);
+                                int32_t D, const float* grad_out, float* grad_w, double* scratch, void* stream);
 
 /* ---- the `fbank` baseline upstream (BASELINE configs[0]) --------------------------------------------------------
  * Replaces get_extracter(fbank.yaml) + UpstreamExpert.forward of upstream/baseline (extracter.py:32-90,

@@ -16,7 +16,11 @@ S3ENC_MAX_CONV = 16
 F32, BF16, F16, F32X3 = 0, 1, 2, 3
 DTYPES = {"fp32": F32, "f32": F32, "float32": F32, "bf16": BF16, "bfloat16": BF16, "fp16": F16, "f16": F16,
           "float16": F16, "fp32x3": F32X3, "f32x3": F32X3, "bf16x3": F32X3}
-FAMILY = {"hubert": 0, "wav2vec2": 1, "wavlm": 2}
+FAMILY = {"hubert": 0, "wav2vec2": 1, "wavlm": 2, "distiller": 3}
+SEL_HIDDEN, SEL_LAYER_OUT, SEL_FFN_OUT = 0, 1, 2
+SELECTIONS = {None: SEL_HIDDEN, "hidden_states": SEL_HIDDEN, "fairseq_layers": SEL_LAYER_OUT,
+              "fairseq_layers_before_residual": SEL_FFN_OUT}
+ABI_VERSION = 2
 
 
 class S3Config(C.Structure):
@@ -27,8 +31,13 @@ class S3Config(C.Structure):
         ("embed_dim", C.c_int32), ("ffn_dim", C.c_int32), ("heads", C.c_int32), ("layer_norm_first", C.c_int32),
         ("conv_pos", C.c_int32), ("conv_pos_groups", C.c_int32), ("normalize", C.c_int32), ("rel_pos", C.c_int32),
         ("num_buckets", C.c_int32), ("max_distance", C.c_int32), ("gru_rel_pos", C.c_int32),
-        ("compute_dtype", C.c_int32),
+        ("compute_dtype", C.c_int32), ("no_feature_layer_norm", C.c_int32), ("pred_heads", C.c_int32),
     ]
+
+
+class S3ForwardOpts(C.Structure):
+    _fields_ = [("selection", C.c_int32), ("out_dtype", C.c_int32), ("featurize", C.c_int32),
+                ("feat_normalize", C.c_int32), ("feat_w", C.POINTER(C.c_float))]
 
 
 class S3Tensor(C.Structure):
@@ -57,6 +66,8 @@ _PROTOS = {
     "s3enc_downsample_rate": (C.c_int, [_VP, C.POINTER(_I32)]),
     "s3enc_valid_frames": (C.c_int, [_VP, _I64, _I64, C.POINTER(_I32)]),
     "s3enc_forward": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(_I64), _I32, _I64, _VP, _I64, _VP]),
+    "s3enc_forward_ex": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(_I64), _I32, _I64, C.POINTER(S3ForwardOpts), _VP, _I64, _VP]),
+    "s3enc_num_states": (C.c_int, [_VP, _I32, C.POINTER(_I32)]),
     "s3enc_forward_padded": (C.c_int, [_VP, _VP, _I64, C.POINTER(_I64), _I32, _I64, _VP, _I64, _VP]),
     "s3enc_set_layer_events": (C.c_int, [_VP, C.POINTER(_VP), _I32]),
     "s3enc_profile_enable": (C.c_int, [_VP, _I32]),
@@ -67,10 +78,14 @@ _PROTOS = {
     "s3enc_op_gemm": (C.c_int, [_I32, _VP, _I64, _I64, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _VP, _VP, _VP, _VP,
                                 _I64, _I64, _VP]),
     "s3enc_op_layernorm": (C.c_int, [_I32, _VP, _VP, _VP, _I32, _I32, _I32, _VP, _VP, _VP]),
-    "s3enc_op_attention": (C.c_int, [_I32, _VP, _VP, _VP, _I32, _I32, _I32, _VP, _VP, _VP]),
+    "s3enc_op_attention": (C.c_int, [_I32, _VP, _VP, _VP, _I32, _I32, _I32, _VP, _I32, _VP, _VP]),
+    "s3enc_op_conv0": (C.c_int, [_I32, C.POINTER(_VP), C.POINTER(_I64), _I32, _I64, _I32, _VP, _VP, _VP, _VP, _VP, _VP, _I32,
+                                 _I32, _VP, _VP]),
+    "s3enc_op_wavlm_gate": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _VP, _VP]),
     "s3enc_op_posconv": (C.c_int, [_I32, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _VP, _VP]),
     "s3enc_weighted_sum": (C.c_int, [_VP, _I64, _I32, C.POINTER(C.c_float), _I32, _I64, _I32, _VP, _VP]),
-    "s3enc_weighted_sum_backward": (C.c_int, [_VP, _I64, _I32, _I32, _I64, _I32, _VP, _VP, _VP]),
+    "s3enc_weighted_sum_backward_scratch": (_I64, [_I64, _I32]),
+    "s3enc_weighted_sum_backward": (C.c_int, [_VP, _I64, _I32, _I32, _I64, _I32, _VP, _VP, _VP, _VP]),
     "s3enc_fbank_num_frames": (C.c_int, [C.POINTER(S3FbankConfig), _I64, C.POINTER(_I32)]),
     "s3enc_fbank_forward": (C.c_int, [C.POINTER(S3FbankConfig), _VP, C.POINTER(_I64), _I32, _VP, _I64, _I32, _VP]),
 }
@@ -102,6 +117,8 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    if lib.s3enc_version() != ABI_VERSION:
+        raise S3EncError(f"{LIB_PATH} has ABI version {lib.s3enc_version()}, this package needs {ABI_VERSION}: rebuild it")
     _lib = lib
     return lib
 
@@ -140,4 +157,6 @@ def make_config(cfg, dtype: str) -> S3Config:
     if dtype not in DTYPES:
         raise S3EncError(f"unknown dtype {dtype!r}; use one of fp32 / bf16 / fp16")
     c.compute_dtype = DTYPES[dtype]
+    c.no_feature_layer_norm = int(not cfg.feature_layer_norm)
+    c.pred_heads = int(cfg.pred_heads)
     return c

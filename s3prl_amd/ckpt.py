@@ -2,7 +2,11 @@
 
 * HuBERT   ``{"task_cfg", "model_cfg", "model_weight", "dictionaries_symbols"}``  (hubert/convert.py:37-56)
 * wav2vec2 ``{"task_cfg", "model_cfg", "model_weight"}``                          (wav2vec2/convert.py:26-39)
-* WavLM    ``{"cfg", "model"}``                                                    (wavlm/expert.py:37-40)
+* WavLM / UniSpeech-SAT ``{"cfg", "model"}``                      (wavlm/expert.py:37-40, unispeech_sat/expert.py:36-39)
+* DistilHuBERT ``{"Config": {"distiller": {...}}, "Distiller": state_dict}``      (distiller/builder.py:41-58,119-122)
+
+plus the fairseq layout ``{"cfg": {"task", "model"}, "model"}`` that ``hubert_custom(fairseq=True)`` /
+``wav2vec2_custom(fairseq=True)`` convert first (hubert/convert.py:22-40, wav2vec2/convert.py:14-24).
 
 Only the hot-path tensors are kept (``mask_emb``, ``label_embs_concat``, ``final_proj``, ``quantizer.*``,
 ``project_q`` … are unused at inference).  Also writes the same formats from synthetic weights.
@@ -14,13 +18,14 @@ from typing import Dict, Tuple
 
 import numpy as np
 
-from .config import EncoderConfig, config_from_dicts
+from .config import EncoderConfig, config_from_dicts, config_from_distiller
 from .synth import param_shapes
 
 _REQUIRED = {
     "hubert": ["task_cfg", "model_cfg", "model_weight", "dictionaries_symbols"],
     "wav2vec2": ["task_cfg", "model_cfg", "model_weight"],
     "wavlm": ["cfg", "model"],
+    "distiller": ["Config", "Distiller"],
 }
 
 
@@ -46,6 +51,9 @@ def load_checkpoint(ckpt: str, family: str) -> Tuple[EncoderConfig, Dict[str, np
     if family == "wavlm":
         cfg = config_from_dicts("wavlm", _plain(state["cfg"]))
         sd = state["model"]
+    elif family == "distiller":
+        cfg = config_from_distiller(_plain(_plain(state["Config"])["distiller"]))
+        sd = state["Distiller"]
     else:
         cfg = config_from_dicts(family, _plain(state["model_cfg"]), _plain(state["task_cfg"]))
         sd = state["model_weight"]
@@ -73,7 +81,15 @@ def save_checkpoint(path: str, cfg: EncoderConfig, weights: Dict[str, np.ndarray
         conv_pos=cfg.conv_pos, conv_pos_groups=cfg.conv_pos_groups, activation_fn="gelu",
         conv_feature_layers=str([tuple(t) for t in cfg.conv_layers]),
     )
-    if cfg.family == "wavlm":
+    if cfg.family == "distiller":
+        d = dict(extractor_mode=cfg.extractor_mode, extractor_conv_feature_layers=model_cfg["conv_feature_layers"],
+                 conv_pos=cfg.conv_pos, conv_pos_groups=cfg.conv_pos_groups, encoder_layers=cfg.encoder_layers,
+                 encoder_embed_dim=cfg.encoder_embed_dim, encoder_ffn_embed_dim=cfg.encoder_ffn_embed_dim,
+                 encoder_attention_heads=cfg.encoder_attention_heads, layer_norm_first=cfg.layer_norm_first,
+                 final_dim=cfg.encoder_embed_dim, n_tasks=cfg.pred_heads, task_emb_type="expand-last",
+                 out_layer_type="expand-last")
+        torch.save({"Config": {"distiller": d}, "Distiller": sd}, path)
+    elif cfg.family == "wavlm":
         model_cfg.update(normalize=cfg.normalize, relative_position_embedding=cfg.relative_position_embedding,
                          num_buckets=cfg.num_buckets, max_distance=cfg.max_distance, gru_rel_pos=cfg.gru_rel_pos)
         torch.save({"cfg": model_cfg, "model": sd}, path)
@@ -82,3 +98,35 @@ def save_checkpoint(path: str, cfg: EncoderConfig, weights: Dict[str, np.ndarray
                     "model_weight": sd, "dictionaries_symbols": [["a"] * 8]}, path)
     else:
         torch.save({"task_cfg": {"normalize": cfg.normalize}, "model_cfg": model_cfg, "model_weight": sd}, path)
+
+
+def convert_fairseq_checkpoint(path: str, family: str, refresh: bool = False) -> str:
+    """``<stem>.converted.pt`` next to a fairseq checkpoint, in the reference's converted format — what
+    ``load_and_convert_fairseq_ckpt`` writes (hubert/convert.py:22-40, wav2vec2/convert.py:14-24), without importing
+    the ``fairseq`` package: the file is unpickled with torch and ``cfg`` may be a dict or an OmegaConf container
+    (unpickling the latter needs ``omegaconf`` to be importable; if it is not, the error says so)."""
+    import os
+
+    import torch
+
+    out = os.path.join(os.path.dirname(os.path.abspath(path)), os.path.splitext(os.path.basename(path))[0] + ".converted.pt")
+    if os.path.isfile(out) and not refresh:
+        return out
+    try:
+        state = torch.load(path, map_location="cpu", weights_only=False)
+    except ModuleNotFoundError as e:  # pragma: no cover - depends on the pickled classes
+        raise RuntimeError(f"{path}: unpickling this fairseq checkpoint needs the module {e.name!r}; convert it with "
+                           f"s3prl's upstream/{family}/convert.py where fairseq is installed") from e
+    if "cfg" not in state or "model" not in state:
+        raise ValueError(f"{path} is not a fairseq checkpoint (needs 'cfg' and 'model')")
+    cfg = state["cfg"]
+    if not isinstance(cfg, dict):
+        from omegaconf import OmegaConf  # only reachable when omegaconf unpickled the object above
+
+        cfg = OmegaConf.to_container(cfg)
+    conv = {"task_cfg": _plain(cfg["task"]), "model_cfg": _plain(cfg["model"]), "model_weight": state["model"]}
+    if family == "hubert":
+        dicts = (state.get("task_state") or {}).get("dictionaries") or []
+        conv["dictionaries_symbols"] = [list(getattr(d, "symbols", d)) for d in dicts]
+    torch.save(conv, out)
+    return out

@@ -58,16 +58,21 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnParams p) {
             qf[4 * i + 3] = t.w;
         }
     }
-    // WavLM: this head's (2T-1)-entry relative-position table is gathered once per workgroup into LDS — every score
-    // element needs table[(key - query) + T - 1], and a per-element global gather would bound the kernel
+    // WavLM: the window of this head's relative-position table that the workgroup's 128 queries can meet (T + 127
+    // entries: key - query in [-(q0 + 127), T - 1 - q0]) is gathered once into LDS from the (2R+1)-entry global table,
+    // clamped to |key - query| <= R = max_distance where the bucket saturates (wavlm/modules.py:436-444); a per-element
+    // global gather would bound the kernel
     extern __shared__ float bias_s[];
     const float* btab = nullptr;
     if (p.bias_table) {
-        const float* src = p.bias_table + (long)head * (2 * p.T - 1);
-        for (int i = threadIdx.x; i < 2 * p.T - 1; i += 256) bias_s[i] = src[i];
+        const int R = p.table_R;
+        const float* src = p.bias_table + (long)head * (2 * R + 1) + R;
+        const int rel0 = -((int)blockIdx.x * QT + QT - 1);  // smallest key - query this workgroup can meet
+        for (int i = threadIdx.x; i < p.T + QT - 1; i += 256) bias_s[i] = src[min(max(rel0 + i, -R), R)];
         btab = bias_s;  // made visible by the first __syncthreads() of the key loop
     }
     const float gate = (btab && p.gate) ? p.gate[((long)b * p.H + head) * p.T + q_c] : 1.f;
+    const int bias_off = (int)blockIdx.x * QT + QT - 1;  // window index = (key - query) + bias_off
 
     f32x16 o0, o1;
 #pragma unroll
@@ -118,7 +123,7 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = kt * KT + crow(r, half);
-                if (key < p.T) s[r] += gate * btab[key - q_c + p.T - 1];
+                if (key < p.T) s[r] += gate * btab[key - q_c + bias_off];
             }
         }
         if (kt * KT + KT > valid) {
@@ -209,16 +214,21 @@ __global__ __launch_bounds__(256, 4) void attn_h16_kernel(AttnParams p) {
 #pragma unroll
     for (int st = 0; st < 4; ++st) qf[st] = *(const uint4*)(base + (long)q_c * ld + st * 16 + 8 * half);
 
-    // WavLM: this head's (2T-1)-entry relative-position table is gathered once per workgroup into LDS — every score
-    // element needs table[(key - query) + T - 1], and a per-element global gather would bound the kernel
+    // WavLM: the window of this head's relative-position table that the workgroup's 128 queries can meet (T + 127
+    // entries: key - query in [-(q0 + 127), T - 1 - q0]) is gathered once into LDS from the (2R+1)-entry global table,
+    // clamped to |key - query| <= R = max_distance where the bucket saturates (wavlm/modules.py:436-444); a per-element
+    // global gather would bound the kernel
     extern __shared__ float bias_s[];
     const float* btab = nullptr;
     if (p.bias_table) {
-        const float* src = p.bias_table + (long)head * (2 * p.T - 1);
-        for (int i = threadIdx.x; i < 2 * p.T - 1; i += 256) bias_s[i] = src[i];
+        const int R = p.table_R;
+        const float* src = p.bias_table + (long)head * (2 * R + 1) + R;
+        const int rel0 = -((int)blockIdx.x * QT + QT - 1);  // smallest key - query this workgroup can meet
+        for (int i = threadIdx.x; i < p.T + QT - 1; i += 256) bias_s[i] = src[min(max(rel0 + i, -R), R)];
         btab = bias_s;  // made visible by the first __syncthreads() of the key loop
     }
     const float gate = (btab && p.gate) ? p.gate[((long)b * p.H + head) * p.T + q_c] : 1.f;
+    const int bias_off = (int)blockIdx.x * QT + QT - 1;  // window index = (key - query) + bias_off
 
     f32x16 o0, o1;
 #pragma unroll
@@ -284,7 +294,7 @@ __global__ __launch_bounds__(256, 4) void attn_h16_kernel(AttnParams p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = k0 + crow(r, half);
-                    if (key < p.T) sc[r] += gate * btab[key - q_c + p.T - 1];
+                    if (key < p.T) sc[r] += gate * btab[key - q_c + bias_off];
                 }
             }
             if (k0 + 32 > valid) {
@@ -360,7 +370,7 @@ __global__ __launch_bounds__(256, 3) void attn_x3_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char dyn_x3[];
     u16* Ks = (u16*)dyn_x3;                       // [plane][buffer][KBUF16]
     u16* Vt = Ks + 4 * KBUF16;                    // [plane][buffer][VBUF16]
-    float* bias_s = (float*)(Vt + 4 * VBUF16);    // WavLM: the head's (2T-1)-entry table
+    float* bias_s = (float*)(Vt + 4 * VBUF16);    // WavLM: the workgroup's (T+127)-entry table window
     const int b = blockIdx.z, head = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
@@ -379,11 +389,14 @@ __global__ __launch_bounds__(256, 3) void attn_x3_kernel(AttnParams p) {
     }
     const float* btab = nullptr;
     if (p.bias_table) {
-        const float* src = p.bias_table + (long)head * (2 * p.T - 1);
-        for (int i = threadIdx.x; i < 2 * p.T - 1; i += 256) bias_s[i] = src[i];
+        const int R = p.table_R;
+        const float* src = p.bias_table + (long)head * (2 * R + 1) + R;
+        const int rel0 = -((int)blockIdx.x * QT + QT - 1);  // smallest key - query this workgroup can meet
+        for (int i = threadIdx.x; i < p.T + QT - 1; i += 256) bias_s[i] = src[min(max(rel0 + i, -R), R)];
         btab = bias_s;  // made visible by the first __syncthreads()
     }
     const float gate = (btab && p.gate) ? p.gate[((long)b * p.H + head) * p.T + q_c] : 1.f;
+    const int bias_off = (int)blockIdx.x * QT + QT - 1;  // window index = (key - query) + bias_off
 
     f32x16 o0, o1;
 #pragma unroll
@@ -457,7 +470,7 @@ __global__ __launch_bounds__(256, 3) void attn_x3_kernel(AttnParams p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = k0 + crow(r, half);
-                    if (key < p.T) sc[r] += gate * btab[key - q_c + p.T - 1];
+                    if (key < p.T) sc[r] += gate * btab[key - q_c + bias_off];
                 }
             }
             if (k0 + 32 > valid) {
@@ -568,8 +581,8 @@ __global__ __launch_bounds__(256) void wavlm_gate_kernel(const float* x, const f
 hipError_t launch_attention(int dtype, const AttnParams& p, hipStream_t s) {
     if (p.B <= 0 || p.T <= 0) return hipSuccess;
     dim3 grid((p.T + QT - 1) / QT, p.H, p.B), block(256);
-    const size_t dyn = p.bias_table ? (size_t)(2 * p.T - 1) * sizeof(float) : 0;  // the head's relative-position table
-    if (dyn > 24 * 1024) return hipErrorInvalidValue;  // T <= 3072 frames (61 s); beyond that the table would not fit beside K/V
+    const size_t dyn = p.bias_table ? (size_t)(p.T + QT - 1) * sizeof(float) : 0;  // the workgroup's table window
+    if (dyn > 24 * 1024) return hipErrorInvalidValue;  // T <= 6017 frames (120 s): the window must fit beside K/V (engine checks)
     switch (dtype) {
         case F32: hipLaunchKernelGGL(attn_f32_kernel, grid, block, dyn, s, p); break;
         case BF16: hipLaunchKernelGGL(attn_h16_kernel<bf16_tag>, grid, block, dyn, s, p); break;

@@ -7,6 +7,7 @@
 //   fc2(+residual), LN }  with every hidden-state tap written straight into the caller's (NL+1, B, T, D) slab.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -88,6 +89,45 @@ struct DevBuf {
         hipError_t e = hipMalloc(&p, n);
         if (e == hipSuccess) bytes = n;
         return e;
+    }
+    // Growth on the forward path, ordered on `st` instead of synchronising the device: the old block is released with
+    // hipFreeAsync (it may still be read by launches already enqueued on `st`) and the new one comes from the
+    // stream-ordered allocator, 25 % larger than asked so a serving loop with drifting batch shapes settles after a few
+    // growths.  Falls back to the synchronising path if the runtime has no stream-ordered pool.
+    hipError_t ensure_on_stream(size_t n, hipStream_t st) {
+        if (n <= bytes) return hipSuccess;
+        const size_t want = n + n / 4;
+        void* np = nullptr;
+        hipError_t e = hipMallocAsync(&np, want, st);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return ensure(want);
+        }
+        if (p) {
+            e = hipFreeAsync(p, st);
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                (void)hipStreamSynchronize(st);
+                (void)hipFree(p);
+            }
+        }
+        p = np;
+        bytes = want;
+        return hipSuccess;
+    }
+};
+
+// current-device RAII: the entry points never leave the caller's (torch's) current device changed
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        int cur = -1;
+        if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
     }
 };
 
@@ -181,9 +221,10 @@ struct s3enc_encoder {
     DevBuf fln_g, fln_b, proj_w, proj_b, pos_w, pos_b, eln_g, eln_b;
     DevBuf proj_w3, pos_w3;  // S3ENC_F32X3
     std::vector<LayerW> layers;
-    std::vector<float> rel_emb;  // host copy of relative_attention_bias.weight [buckets][H]
-    DevBuf rel_table;
-    int rel_table_T = -1;
+    DevBuf rel_table;  // WavLM: [H][2R+1], entry (h, rel + R), R = max_distance (the bucket saturates there)
+    int rel_R = 0;
+    DevBuf head_w1, head_b1, head_w2, head_b2, head_w13, head_w23;  // DistilHuBERT prediction heads (+ S3ENC_F32X3 images)
+    DevBuf wsum_part;  // persistent partials of s3enc_weighted_sum_backward
 
     DevBuf ws;      // activation workspace
     DevBuf small;   // tables, stats
@@ -201,6 +242,7 @@ struct s3enc_encoder {
     std::vector<double> kflops, kbytes;
     std::vector<long> klaunches;
     std::vector<ProfRec> recs;
+    std::vector<hipEvent_t> ev_pool;  // timing events are recycled across profile_reset, never created per forward twice
 
     // debug taps of the last forward
     struct Tap {
@@ -215,6 +257,7 @@ struct s3enc_encoder {
             (void)hipEventDestroy(r.a);
             (void)hipEventDestroy(r.b);
         }
+        for (auto ev : ev_pool) (void)hipEventDestroy(ev);
         for (int i = 0; i < RING; ++i)
             if (slot_ev[i]) (void)hipEventDestroy(slot_ev[i]);
         if (pinned) (void)hipHostFree(pinned);
@@ -228,6 +271,14 @@ struct s3enc_encoder {
         kbytes.push_back(0);
         klaunches.push_back(0);
         return (int)kinds.size() - 1;
+    }
+    bool take_event(hipEvent_t* ev) {
+        if (!ev_pool.empty()) {
+            *ev = ev_pool.back();
+            ev_pool.pop_back();
+            return true;
+        }
+        return hipEventCreate(ev) == hipSuccess;
     }
 };
 
@@ -246,7 +297,11 @@ struct Prof {
         e->klaunches[k] += 1;
         ProfRec r;
         r.kind = k;
-        if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+        if (!e->take_event(&r.a)) return;
+        if (!e->take_event(&r.b)) {
+            e->ev_pool.push_back(r.a);
+            return;
+        }
         (void)hipEventRecord(r.a, st);
         e->recs.push_back(r);
         idx = (int)e->recs.size() - 1;
@@ -292,8 +347,8 @@ int valid_frames(const s3enc_config& c, long length, long n_max) {
     const long T = conv_len(c, n_max, c.n_conv);
     if (T <= 0) return 0;
     long v;
-    if (c.family == S3ENC_WAV2VEC2) {
-        v = conv_len(c, length, c.n_conv);  // wav2vec2_model.py:2652-2669
+    if (c.family == S3ENC_WAV2VEC2 || c.family == S3ENC_DISTILLER) {
+        v = conv_len(c, length, c.n_conv);  // wav2vec2_model.py:2652-2669; distiller/model.py:271-285
     } else {
         const long chunk = n_max / T;  // hubert_model.py:454-464
         v = (length + chunk - 1) / chunk;
@@ -303,8 +358,34 @@ int valid_frames(const s3enc_config& c, long length, long n_max) {
     return (int)v;
 }
 
+// WavLM bucket table (wavlm/modules.py:418-462): table[h][rel + R] = E[bucket(rel)][h] for rel = key - query in [-R, R]
+void build_rel_table(const s3enc_config& c, const std::vector<float>& emb, int R, std::vector<float>& table) {
+    const int H = c.heads, nb = c.num_buckets / 2, max_exact = nb / 2;
+    const int W = 2 * R + 1;
+    table.resize((size_t)H * W);
+    const float denom = (float)std::log((double)c.max_distance / (double)max_exact);
+    for (int idx = 0; idx < W; ++idx) {
+        const int rel = idx - R;
+        int bucket = rel > 0 ? nb : 0;
+        const int a = rel < 0 ? -rel : rel;
+        if (a < max_exact) {
+            bucket += a;
+        } else {
+            float v = std::log((float)a / (float)max_exact);
+            v = v / denom;
+            v = v * (float)(nb - max_exact);
+            int large = max_exact + (int)v;
+            if (large > nb - 1) large = nb - 1;
+            bucket += large;
+        }
+        for (int h = 0; h < H; ++h) table[(size_t)h * W + idx] = emb[(size_t)bucket * H + h];
+    }
+}
+
 int check_config(const s3enc_config& c) {
-    if (c.family < 0 || c.family > 2) return fail("config: unknown family");
+    if (c.family < 0 || c.family > 3) return fail("config: unknown family");
+    if (c.pred_heads < 0 || c.pred_heads > 16) return fail("config: pred_heads out of range");
+    if (c.pred_heads && c.family != S3ENC_DISTILLER) return fail("config: pred_heads is a DistilHuBERT feature");
     if (c.n_conv < 2 || c.n_conv > S3ENC_MAX_CONV) return fail("config: n_conv out of range");
     if (c.conv_kernel[0] != 10) return fail("config: the conv0 kernel is specialised for kernel width 10");
     if (c.conv_dim % 32 || c.conv_dim > 1024) return fail("config: conv_dim must be a multiple of 32, <= 1024");
@@ -319,6 +400,7 @@ int check_config(const s3enc_config& c) {
     if (c.rel_pos && c.family != S3ENC_WAVLM) return fail("config: rel_pos is a WavLM feature");
     if (c.rel_pos && (c.num_buckets < 4 || c.max_distance <= c.num_buckets / 4))
         return fail("config: bad num_buckets / max_distance");
+    if (c.rel_pos && c.max_distance > 8192) return fail("config: max_distance > 8192");
     return 0;
 }
 
@@ -337,7 +419,8 @@ int s3enc_create(const s3enc_config* cfg, const s3enc_tensor* tensors, int32_t n
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail("s3enc_create: no HIP device visible — libs3enc has no CPU fallback");
     if (device < 0 || device >= ndev) return fail("s3enc_create: device index out of range");
-    HIP_TRY(hipSetDevice(device));
+    DeviceGuard dg(device);
+    if (!dg.ok) return fail("s3enc_create: hipSetDevice failed");
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
@@ -405,10 +488,12 @@ int s3enc_create(const s3enc_config* cfg, const s3enc_tensor* tensors, int32_t n
             UP(upload_f32(e->gn_b, t));
         }
     }
-    GET("layer_norm.weight", C, t);
-    UP(upload_f32(e->fln_g, t));
-    GET("layer_norm.bias", C, t);
-    UP(upload_f32(e->fln_b, t));
+    if (!c.no_feature_layer_norm) {
+        GET("layer_norm.weight", C, t);
+        UP(upload_f32(e->fln_g, t));
+        GET("layer_norm.bias", C, t);
+        UP(upload_f32(e->fln_b, t));
+    }
     GET("post_extract_proj.weight", (long)D * C, t);
     UP(upload_cvt(e->proj_w, t, e->dtype));
     if (e->x3) UP(upload_x3(e->proj_w3, t, D, C));
@@ -489,7 +574,32 @@ int s3enc_create(const s3enc_config* cfg, const s3enc_tensor* tensors, int32_t n
         }
     }
     if (c.rel_pos) {
-        GET("encoder.layers.0.self_attn.relative_attention_bias.weight", (long)c.num_buckets * H, e->rel_emb);
+        // bucket(rel) (wavlm/modules.py:418-446) is constant for |rel| >= max_distance, so ONE (H, 2R+1) table with
+        // R = max_distance serves every sequence length: nothing is rebuilt when T changes between batches
+        std::vector<float> emb, table;
+        GET("encoder.layers.0.self_attn.relative_attention_bias.weight", (long)c.num_buckets * H, emb);
+        e->rel_R = c.max_distance;
+        build_rel_table(c, emb, e->rel_R, table);
+        UP(upload_f32(e->rel_table, table));
+    }
+    if (c.pred_heads) {
+        // output_layer = Linear(D, N*D) -> GELU -> SplitLinear(D, N, D) (distiller/model.py:155-161): SplitLinear's
+        // weight is (N, Din, Dout) (module.py:66-68); each head becomes an (out, in) row-major GEMM operand
+        const int NH = c.pred_heads;
+        GET("output_layer.0.weight", (long)NH * D * D, t);
+        UP(upload_cvt(e->head_w1, t, e->dtype));
+        if (e->x3) UP(upload_x3(e->head_w13, t, (long)NH * D, D));
+        GET("output_layer.0.bias", (long)NH * D, t);
+        UP(upload_f32(e->head_b1, t));
+        GET("output_layer.2.weight", (long)NH * D * D, t);
+        t2.resize(t.size());
+        for (int k = 0; k < NH; ++k)
+            for (int i = 0; i < D; ++i)
+                for (int n = 0; n < D; ++n) t2[((long)k * D + n) * D + i] = t[((long)k * D + i) * D + n];
+        UP(upload_cvt(e->head_w2, t2, e->dtype));
+        if (e->x3) UP(upload_x3(e->head_w23, t2, (long)NH * D, D));
+        GET("output_layer.2.bias", (long)NH * D, t);
+        UP(upload_f32(e->head_b2, t));
     }
 #undef GET
 #undef UP
@@ -505,7 +615,7 @@ int s3enc_create(const s3enc_config* cfg, const s3enc_tensor* tensors, int32_t n
 
 int s3enc_destroy(s3enc_handle h) {
     if (!h) return 0;
-    (void)hipSetDevice(h->device);
+    DeviceGuard dg(h->device);
     (void)hipDeviceSynchronize();
     delete h;
     return 0;
@@ -545,35 +655,76 @@ struct Bump {
     }
 };
 
-// WavLM bucket table: table[h][idx], idx = (j - i) + (T-1)   (wavlm/modules.py:418-462)
-void build_rel_table(const s3enc_config& c, const std::vector<float>& emb, int T, std::vector<float>& table) {
-    const int H = c.heads, nb = c.num_buckets / 2, max_exact = nb / 2;
-    table.resize((size_t)H * (2 * T - 1));
-    const float denom = (float)std::log((double)c.max_distance / (double)max_exact);
-    for (int idx = 0; idx < 2 * T - 1; ++idx) {
-        const int rel = idx - (T - 1);
-        int bucket = rel > 0 ? nb : 0;
-        const int a = rel < 0 ? -rel : rel;
-        if (a < max_exact) {
-            bucket += a;
-        } else {
-            float v = std::log((float)a / (float)max_exact);
-            v = v / denom;
-            v = v * (float)(nb - max_exact);
-            int large = max_exact + (int)v;
-            if (large > nb - 1) large = nb - 1;
-            bucket += large;
-        }
-        for (int h = 0; h < H; ++h) table[(size_t)h * (2 * T - 1) + idx] = emb[(size_t)bucket * H + h];
-    }
+struct FwdOpts {
+    int selection = S3ENC_SEL_HIDDEN;
+    int out_dtype = F32;
+    bool featurize = false;
+    int feat_norm = 0;
+    const float* w = nullptr;  // host, one per state
+};
+
+int num_states(const s3enc_config& c, int selection) {
+    if (selection == S3ENC_SEL_HIDDEN) return c.encoder_layers + 1 + (c.family == S3ENC_DISTILLER ? c.pred_heads : 0);
+    return c.encoder_layers;
 }
 
+// Where the selected states go: straight into the caller's fp32 slab (the producing kernel writes the slot, nothing is
+// copied), as 16-bit copies next to an internal fp32 residual stream, or only as their term of the Featurizer sum.
+struct Sink {
+    s3enc_encoder* e;
+    hipStream_t st;
+    int mode;  // 0 fp32 slab, 1 16-bit slab, 2 featurize
+    void* out;
+    long stride;
+    int dt;  // the handle's compute dtype (the 16-bit slab's type)
+    long M;
+    int D;
+    const float* w;
+    int norm;
+    bool first = true;
+
+    float* slot32(int si) const { return (mode == 0 && si >= 0) ? (float*)out + (long)si * stride : nullptr; }
+    void* slot16(int si) const { return (mode == 1 && si >= 0) ? (void*)((u16*)out + (long)si * stride) : nullptr; }
+    bool wanted(int si) const { return si >= 0 && (mode != 2 || w[si] != 0.f); }
+    // Featurizer term of state `si`, fused into a row kernel that holds the state as its input (1) or output (2)
+    LnAcc acc(int si, int where) {
+        LnAcc a;
+        if (mode != 2 || si < 0 || w[si] == 0.f) return a;
+        a.acc = (float*)out;
+        a.w = w[si];
+        a.mode = where;
+        a.norm = norm;
+        a.init = first;
+        first = false;
+        return a;
+    }
+    // a state a non-LayerNorm kernel left in fp32 outside the slab: its 16-bit copy / its Featurizer term
+    hipError_t emit(int si, const float* x, bool copy16 = true) {
+        if (si < 0) return hipSuccess;
+        if (mode == 1 && copy16) return launch_emit_state(dt, x, M, D, slot16(si), LnAcc(), st);
+        if (mode == 2 && w[si] != 0.f) return launch_emit_state(F32, x, M, D, nullptr, acc(si, 1), st);
+        return hipSuccess;
+    }
+    hipError_t done(int si) {
+        if (si < 0 || mode == 2 || e->layer_events.empty() || si >= (int)e->layer_events.size()) return hipSuccess;
+        return hipEventRecord(e->layer_events[si], st);
+    }
+};
+
 int forward_impl(s3enc_handle e, const float* const* wav_ptrs_host, const int64_t* lengths, int32_t B, int64_t n_max_in,
-                 float* out, int64_t layer_stride, hipStream_t st) {
+                 const FwdOpts& fo, void* out, int64_t layer_stride, hipStream_t st) {
     const s3enc_config& c = e->cfg;
     const int C = c.conv_dim, D = c.embed_dim, F = c.ffn_dim, H = c.heads, NL = c.encoder_layers;
     const int dt = e->dtype, es = e->es;
+    const bool dist = c.family == S3ENC_DISTILLER;
+    const int NH = dist ? c.pred_heads : 0;
     if (B <= 0) return fail("s3enc_forward: B must be positive");
+    if (fo.selection < 0 || fo.selection > 2) return fail("s3enc_forward: unknown selection");
+    if (dist && fo.selection != S3ENC_SEL_HIDDEN) return fail("s3enc_forward: DistilHuBERT has one selection (its hidden_states list)");
+    const int NS = num_states(c, fo.selection);
+    if (fo.featurize && !fo.w) return fail("s3enc_forward: featurize needs feat_w");
+    if (!fo.featurize && fo.out_dtype != F32 && (fo.out_dtype != dt || dt == F32))
+        return fail("s3enc_forward: out_dtype must be S3ENC_F32 or the handle's own 16-bit compute dtype");
     long n_max = 0;
     for (int b = 0; b < B; ++b) {
         if (lengths[b] <= 0) return fail("s3enc_forward: empty utterance");
@@ -589,14 +740,20 @@ int forward_impl(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
     const long T = L[c.n_conv - 1];
     if (T < 1) return fail("s3enc_forward: input shorter than the receptive field of the conv stack");
     const long M = (long)B * T;
-    if (layer_stride < M * D) return fail("s3enc_forward: layer_stride < B*T*D");
     if (!out) return fail("s3enc_forward: null output");
+    if (!fo.featurize) {
+        if (layer_stride < M * D) return fail("s3enc_forward: layer_stride < B*T*D");
+        if (layer_stride & 3) return fail("s3enc_forward: layer_stride must be a multiple of 4 elements (vector stores)");
+    }
+    if ((uintptr_t)out & 15) return fail("s3enc_forward: out must be 16-byte aligned");
+    if (c.rel_pos && T > 6000) return fail("s3enc_forward: WavLM relative-position window limited to 6000 frames (120 s) per batch");
     std::vector<int> valid(B);
     for (int b = 0; b < B; ++b) {
         valid[b] = valid_frames(c, lengths[b], n_max);
         if (valid[b] < 1) return fail("s3enc_forward: an utterance is too short to produce a valid frame");
     }
-    HIP_TRY(hipSetDevice(e->device));
+    DeviceGuard dg(e->device);
+    if (!dg.ok) return fail("s3enc_forward: hipSetDevice failed");
 
     // ---- small device state: tables + stats ----
     const size_t tbl_bytes = (size_t)B * (8 + 8 + 4);
@@ -607,7 +764,7 @@ int forward_impl(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
         sb.take((size_t)B * sizeof(float2));
         sb.take((size_t)B * C * sizeof(float2));
         sb.take(part_elems * 8);
-        HIP_TRY(e->small.ensure(sb.off + 1024));
+        HIP_TRY(e->small.ensure_on_stream(sb.off + 1024, st));
     }
     Bump sb(e->small.p);
     char* d_tbl = (char*)sb.take(tbl_bytes);
@@ -623,7 +780,7 @@ int forward_impl(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
         HIP_TRY(hipStreamSynchronize(st));
         if (e->pinned) HIP_TRY(hipHostFree(e->pinned));
         e->pinned = nullptr;
-        e->slot_bytes = tbl_bytes * 2 + 4096;
+        e->slot_bytes = tbl_bytes * 4 + 4096;
         HIP_TRY(hipHostMalloc(&e->pinned, e->slot_bytes * s3enc_encoder::RING, hipHostMallocDefault));
     }
     {
@@ -642,13 +799,16 @@ int forward_impl(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
     const bool lnmode = c.extractor_layer_norm != 0;
     const bool prel = c.layer_norm_first != 0;
     const bool gated = c.rel_pos && c.gru_rel_pos;
-    void *actA, *actB, *tmp32, *feat32, *featT, *x32, *xpc, *xT, *qkv, *attn, *tmp1, *tmp2, *hbuf, *gate;
+    const bool featln = !c.no_feature_layer_norm;
+    const bool ffn_tap = fo.selection == S3ENC_SEL_FFN_OUT;
+    const long HW = std::max<long>(F, (long)NH * D);  // widest row of the FFN / prediction-head intermediate
+    void *actA, *actB, *tmp32, *feat32, *featT, *x32, *xpc, *xT, *qkv, *attn, *tmp1, *tmp2, *hbuf, *gate, *ffnbuf;
     for (int pass = 0; pass < 2; ++pass) {
         Bump wb(pass ? e->ws.p : nullptr);
         actA = wb.take((size_t)B * L[0] * C * es);
         actB = wb.take((size_t)B * L[1] * C * es);
         tmp32 = lnmode ? wb.take((size_t)B * L[1] * C * 4) : nullptr;
-        feat32 = wb.take((size_t)M * C * 4);
+        feat32 = featln ? wb.take((size_t)M * C * 4) : nullptr;
         featT = wb.take((size_t)M * C * es);
         x32 = wb.take((size_t)M * D * 4);
         xpc = wb.take((size_t)M * D * 4);
@@ -657,11 +817,29 @@ int forward_impl(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
         attn = wb.take((size_t)M * D * es);
         tmp1 = wb.take((size_t)M * D * 4);
         tmp2 = wb.take((size_t)M * D * 4);
-        hbuf = wb.take((size_t)M * F * es);
+        hbuf = wb.take((size_t)M * HW * es);
         gate = gated ? wb.take((size_t)B * H * T * 4) : nullptr;
-        if (!pass) HIP_TRY(e->ws.ensure(wb.off + 4096));
+        ffnbuf = (ffn_tap && (fo.featurize || fo.out_dtype != F32)) ? wb.take((size_t)M * D * 4) : nullptr;
+        if (!pass) HIP_TRY(e->ws.ensure_on_stream(wb.off + 4096, st));
     }
     e->taps.clear();
+
+    Sink sink{e, st, fo.featurize ? 2 : (fo.out_dtype != F32 ? 1 : 0), out, (long)layer_stride, dt, M, D, fo.w, fo.feat_norm};
+    if (fo.featurize) {
+        bool any = false;
+        for (int i = 0; i < NS; ++i) any = any || fo.w[i] != 0.f;
+        if (!any) HIP_TRY(hipMemsetAsync(out, 0, (size_t)M * D * 4, st));
+    }
+    // state index of each tensor of the forward under this selection (-1: not a state)
+    const bool hid = fo.selection == S3ENC_SEL_HIDDEN && !dist;
+    const bool lay = fo.selection == S3ENC_SEL_LAYER_OUT;
+    auto si_hidden = [&](int l) { return hid ? l : -1; };                             // input of layer l / encoder output
+    auto si_layer_out = [&](int l) { return lay ? l : (dist ? 1 + l : -1); };         // output of layer l
+    auto si_stream = [&](int l) {  // the tensor "residual stream after layer l" as the next layer's input
+        const int a = (l + 1 < NL || !prel) ? si_hidden(l + 1) : -1;  // pre-LN: the encoder output is the normed stream
+        return a >= 0 ? a : si_layer_out(l);
+    };
+    auto other = [&](const float* busy) { return busy == (const float*)x32 ? (float*)xpc : (float*)x32; };
 
     WavTable wt{d_ptrs, d_lens, B, n_max};
     {
@@ -690,11 +868,13 @@ int forward_impl(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
         Prof pr(e, st, "conv0", 2.0 * B * L[0] * C * p.k0, 4.0 * B * n_max + (double)B * L[0] * C * es);
         HIP_TRY(launch_conv0(dt, p, st));
     }
-    // conv1..: implicit GEMM on channel-last activations
+    // conv1..: implicit GEMM on channel-last activations.  The last one feeds LayerNorm(C) in fp32, or — without that
+    // norm (DistilHuBERT) — post_extract_proj directly, in the compute dtype.
     void* cur = actA;
     for (int i = 1; i < c.n_conv; ++i) {
         const bool last = i == c.n_conv - 1;
-        void* dst = last ? feat32 : (cur == actA ? actB : actA);
+        const bool f32out = dt == F32 || (last && featln);
+        void* dst = last ? (featln ? feat32 : featT) : (cur == actA ? actB : actA);
         GemmParams g{};
         g.A = cur;
         g.lda = (long)c.conv_stride[i] * C;
@@ -709,12 +889,12 @@ int forward_impl(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
         g.ldo = C;
         g.o_bs = L[i] * C;
         const double fl = 2.0 * B * L[i] * C * g.K;
-        const double by = ((double)B * L[i - 1] * C + (double)C * g.K) * es + (double)B * L[i] * C * (last ? 4 : es);
+        const double by = ((double)B * L[i - 1] * C + (double)C * g.K) * es + (double)B * L[i] * C * (f32out ? 4 : es);
         char kind[32];
         snprintf(kind, sizeof(kind), "gemm:conv%d", i);
         if (!lnmode) {
             g.act = 1;
-            if (last || dt == F32) g.out32 = (float*)dst; else g.out16 = dst;
+            if (f32out) g.out32 = (float*)dst; else g.out16 = dst;
             Prof pr(e, st, kind, fl, by);
             HIP_TRY(launch_gemm(dt, g, st));
         } else {
@@ -724,33 +904,27 @@ int forward_impl(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
                 Prof pr(e, st, kind, fl, by);
                 HIP_TRY(launch_gemm(dt, g, st));
             }
-            Prof pr(e, st, "layernorm:conv", 0, (double)B * L[i] * C * (4 + (last ? 4 : es)));
+            Prof pr(e, st, "layernorm:conv", 0, (double)B * L[i] * C * (4 + (f32out ? 4 : es)));
             HIP_TRY(launch_layernorm(dt, (const float*)tmp32, (const float*)e->conv[i].lng.p, (const float*)e->conv[i].lnb.p,
-                                     (long)B * L[i], C, 1, (last || dt == F32) ? (float*)dst : nullptr,
-                                     (last || dt == F32) ? nullptr : dst, st));
+                                     (long)B * L[i], C, 1, f32out ? (float*)dst : nullptr, f32out ? nullptr : dst, st));
         }
         char tn[16];
         snprintf(tn, sizeof(tn), "conv%d", i);
-        if (i >= c.n_conv - 3) e->taps[tn] = {dst, (long)B * L[i] * C, last ? F32 : dt};  // earlier ones get overwritten
+        if (i >= c.n_conv - 3) e->taps[tn] = {dst, (long)B * L[i] * C, f32out ? (int)F32 : dt};  // earlier ones get overwritten
         cur = dst;
     }
     // LayerNorm(C) -> post_extract_proj (+ zero padded frames)
-    const void* featA;
-    {
+    if (featln) {
         Prof pr(e, st, "layernorm:feat", 0, (double)M * C * (4 + es));
-        if (dt == F32) {
-            HIP_TRY(launch_layernorm(dt, (const float*)feat32, (const float*)e->fln_g.p, (const float*)e->fln_b.p, M, C, 0,
-                                     (float*)featT, nullptr, st));
-        } else {
-            HIP_TRY(launch_layernorm(dt, (const float*)feat32, (const float*)e->fln_g.p, (const float*)e->fln_b.p, M, C, 0,
-                                     nullptr, featT, st));
-        }
-        featA = featT;
+        HIP_TRY(launch_layernorm(dt, (const float*)feat32, (const float*)e->fln_g.p, (const float*)e->fln_b.p, M, C, 0,
+                                 dt == F32 ? (float*)featT : nullptr, dt == F32 ? nullptr : featT, st));
         e->taps["feat_ln"] = {featT, M * C, dt};
     }
+    const int si_proj = dist ? 0 : -1;  // DistilHuBERT: hidden_states[0] = feat_final, padded frames zeroed in place
+    float* xproj = sink.slot32(si_proj) ? sink.slot32(si_proj) : (float*)x32;
     {
         GemmParams g{};
-        g.A = featA;
+        g.A = featT;
         g.lda = C;
         g.a_bs = T * C;
         g.W = e->proj_w.p;
@@ -761,75 +935,78 @@ int forward_impl(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
         g.K = C;
         g.batches = B;
         g.row_limit = d_valid;
-        g.out32 = (float*)x32;
+        g.out32 = xproj;
+        g.out16 = sink.slot16(si_proj);
         g.ldo = D;
         g.o_bs = T * D;
-        Prof pr(e, st, "gemm:proj", 2.0 * M * D * C, ((double)M * C + (double)D * C) * es + (double)M * D * 4);
-        HIP_TRY(launch_gemm(dt, g, st));
-        e->taps["proj"] = {x32, M * D, F32};
+        {
+            Prof pr(e, st, "gemm:proj", 2.0 * M * D * C, ((double)M * C + (double)D * C) * es + (double)M * D * 4);
+            HIP_TRY(launch_gemm(dt, g, st));
+        }
+        e->taps["proj"] = {xproj, M * D, F32};
+        HIP_TRY(sink.emit(si_proj, xproj, false));
+        HIP_TRY(sink.done(si_proj));
     }
     // positional conv + residual; hidden_states[0]
-    float* hs0 = out;
+    float* x_cur;          // the fp32 residual stream entering the layer loop
+    void* a16_cur = nullptr;  // post-LN 16-bit modes: its 16-bit copy (the q|k|v operand)
     {
+        const int si0 = si_hidden(0);
+        float* pc_out = prel ? (sink.slot32(si0) ? sink.slot32(si0) : other(xproj)) : other(xproj);
         PosConvParams p{};
-        p.x = (const float*)x32;
+        p.x = xproj;
         p.w = e->pos_w.p;
         p.bias = (const float*)e->pos_b.p;
-        p.out = prel ? hs0 : (float*)xpc;
+        p.out = pc_out;
         p.B = B;
         p.T = (int)T;
         p.D = D;
         p.G = c.conv_pos_groups;
         p.K = c.conv_pos;
-        Prof pr(e, st, "posconv", 2.0 * M * D * (D / p.G) * p.K, (double)M * D * 8 + (double)D * (D / p.G) * p.K * 4);
-        if (e->x3) {
-            p.w = e->pos_w3.p;
-            HIP_TRY(launch_posconv16(3, p, st));
-        } else {
-            HIP_TRY(dt == F32 ? launch_posconv(p, st) : launch_posconv16(dt, p, st));
+        {
+            Prof pr(e, st, "posconv", 2.0 * M * D * (D / p.G) * p.K, (double)M * D * 8 + (double)D * (D / p.G) * p.K * 4);
+            if (e->x3) {
+                p.w = e->pos_w3.p;
+                HIP_TRY(launch_posconv16(3, p, st));
+            } else {
+                HIP_TRY(dt == F32 ? launch_posconv(p, st) : launch_posconv16(dt, p, st));
+            }
         }
         e->taps["posconv"] = {p.out, M * D, F32};
-    }
-    if (!prel) {
-        Prof pr(e, st, "layernorm:enc", 0, (double)M * D * (8 + (dt == F32 ? 0 : es)));
-        HIP_TRY(launch_layernorm(dt, (const float*)xpc, (const float*)e->eln_g.p, (const float*)e->eln_b.p, M, D, 0, hs0,
-                                 dt == F32 ? nullptr : xT, st));
-    }
-    if (!e->layer_events.empty()) HIP_TRY(hipEventRecord(e->layer_events[0], st));
-    // WavLM relative-position table for this T
-    const float* d_table = nullptr;
-    if (c.rel_pos) {
-        if (e->rel_table_T != (int)T) {
-            std::vector<float> table;
-            build_rel_table(c, e->rel_emb, (int)T, table);
-            HIP_TRY(hipStreamSynchronize(st));
-            HIP_TRY(upload_f32(e->rel_table, table));
-            e->rel_table_T = (int)T;
+        if (prel) {
+            x_cur = pc_out;
+            if (sink.mode == 1) HIP_TRY(sink.emit(si0, pc_out));  // featurize: ln1 of layer 0 adds this state's term
+            HIP_TRY(sink.done(si0));
+        } else {
+            float* h0 = sink.slot32(si0) ? sink.slot32(si0) : other(pc_out);
+            void* h16 = dt == F32 ? nullptr : (sink.slot16(si0) ? sink.slot16(si0) : xT);
+            Prof pr(e, st, "layernorm:enc", 0, (double)M * D * (8 + (dt == F32 ? 0 : es)));
+            HIP_TRY(launch_layernorm(dt, pc_out, (const float*)e->eln_g.p, (const float*)e->eln_b.p, M, D, 0, h0, h16, st,
+                                     sink.acc(si0, 2)));
+            x_cur = h0;
+            a16_cur = h16;
+            HIP_TRY(sink.done(si0));
         }
-        d_table = (const float*)e->rel_table.p;
     }
+    const float* d_table = c.rel_pos ? (const float*)e->rel_table.p : nullptr;
 
     const double gM = (double)M;
+    int si_cur = si_hidden(0);  // state index of x_cur (pre-LN featurize: its term is added by the LayerNorm that reads it)
     for (int l = 0; l < NL; ++l) {
         LayerW& Lw = e->layers[l];
-        float* x_in = out + (long)l * layer_stride;         // hidden_states[l] (fp32)
-        float* x_out = out + (long)(l + 1) * layer_stride;  // hidden_states[l+1]
         const bool lastl = l == NL - 1;
-        const void* a_in;  // operand of the q|k|v GEMM
+        const void* a_in;       // operand of the q|k|v GEMM
         const float* gate_src;  // WavLM: the attention module's input
         if (prel) {
             Prof pr(e, st, "layernorm:ln1", 0, gM * D * (4 + es));
-            if (dt == F32) {
-                HIP_TRY(launch_layernorm(dt, x_in, (const float*)Lw.ln1g.p, (const float*)Lw.ln1b.p, M, D, 0, (float*)xT, nullptr, st));
-            } else {
-                HIP_TRY(launch_layernorm(dt, x_in, (const float*)Lw.ln1g.p, (const float*)Lw.ln1b.p, M, D, 0,
-                                         gated ? (float*)tmp2 : nullptr, xT, st));
-            }
+            HIP_TRY(launch_layernorm(dt, x_cur, (const float*)Lw.ln1g.p, (const float*)Lw.ln1b.p, M, D, 0,
+                                     dt == F32 ? (float*)xT : (gated ? (float*)tmp2 : nullptr), dt == F32 ? nullptr : xT, st,
+                                     sink.acc(si_cur, 1)));
             a_in = xT;
             gate_src = dt == F32 ? (const float*)xT : (const float*)tmp2;
         } else {
-            a_in = dt == F32 ? (const void*)x_in : (const void*)xT;
-            gate_src = x_in;
+            a_in = dt == F32 ? (const void*)x_cur : (const void*)a16_cur;
+            gate_src = x_cur;
         }
         if (gated) {
             Prof pr(e, st, "wavlm_gate", 2.0 * M * H * 64 * 8, gM * D * 4);
@@ -862,6 +1039,7 @@ int forward_impl(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
             a.T = (int)T;
             a.H = H;
             a.bias_table = d_table;
+            a.table_R = e->rel_R;
             a.gate = gated ? (const float*)gate : nullptr;
             Prof pr(e, st, "attention", 4.0 * B * H * (double)T * T * 64, gM * 4 * D * es);
             HIP_TRY(launch_attention(e->x3 ? 3 : dt, a, st));
@@ -879,7 +1057,7 @@ int forward_impl(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
             g.K = D;
             g.batches = 1;
             g.ldo = D;
-            g.residual = x_in;
+            g.residual = x_cur;
             g.out32 = (float*)tmp1;
             Prof pr(e, st, "gemm:out_proj", 2.0 * gM * D * D, (gM * D + (double)D * D) * es + gM * D * 8);
             HIP_TRY(launch_gemm(dt, g, st));
@@ -916,7 +1094,12 @@ int forward_impl(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
             Prof pr(e, st, "gemm:fc1", 2.0 * gM * F * D, (gM * D + (double)F * D + gM * F) * es);
             HIP_TRY(launch_gemm(dt, g, st));
         }
-        {   // fc2 + bias + residual
+        // fc2 + bias + residual.  pre-LN: the result IS the residual stream after the layer (a state for l < NL-1, and
+        // for the fairseq_layers / DistilHuBERT selections); post-LN: it feeds final_layer_norm.
+        const int si_next = si_stream(l);
+        float* x_next = sink.slot32(si_next) ? sink.slot32(si_next) : other(x_cur);
+        float* fc2_dst = prel ? x_next : (float*)tmp1;
+        {
             GemmParams g{};
             g.A = hbuf;
             g.lda = F;
@@ -928,22 +1111,97 @@ int forward_impl(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
             g.K = F;
             g.batches = 1;
             g.ldo = D;
-            g.residual = ffn_res;
-            // pre-LN: the raw residual stream IS hidden_states[l+1] (except after the last layer, which is normed)
-            g.out32 = prel ? (lastl ? (float*)tmp2 : x_out) : (float*)tmp1;
-            Prof pr(e, st, "gemm:fc2", 2.0 * gM * D * F, (gM * F + (double)D * F) * es + gM * D * 8);
-            HIP_TRY(launch_gemm(dt, g, st));
+            if (ffn_tap) {
+                // "fairseq_layers_before_residual": the GEMM exports fc2(x) + bias, the residual is re-applied by an
+                // elementwise add in the same order as the fused epilogue (bit-identical stream)
+                float* f_out = sink.slot32(l) ? sink.slot32(l) : (float*)ffnbuf;
+                g.out32 = f_out;
+                g.out16 = sink.slot16(l);
+                {
+                    Prof pr(e, st, "gemm:fc2", 2.0 * gM * D * F, (gM * F + (double)D * F) * es + gM * D * 4);
+                    HIP_TRY(launch_gemm(dt, g, st));
+                }
+                HIP_TRY(sink.emit(l, f_out, false));
+                HIP_TRY(sink.done(l));
+                Prof pr(e, st, "residual_add", 0, gM * D * 12);
+                HIP_TRY(launch_add(f_out, ffn_res, fc2_dst, M * D, st));
+            } else {
+                g.residual = ffn_res;
+                g.out32 = fc2_dst;
+                g.out16 = prel ? sink.slot16(si_next) : nullptr;
+                Prof pr(e, st, "gemm:fc2", 2.0 * gM * D * F, (gM * F + (double)D * F) * es + gM * D * 8);
+                HIP_TRY(launch_gemm(dt, g, st));
+            }
         }
         if (!prel) {
+            void* h16 = dt == F32 ? nullptr : (sink.slot16(si_next) ? sink.slot16(si_next) : xT);
             Prof pr(e, st, "layernorm:ln2", 0, gM * D * (8 + (dt == F32 ? 0 : es)));
-            HIP_TRY(launch_layernorm(dt, (const float*)tmp1, (const float*)Lw.ln2g.p, (const float*)Lw.ln2b.p, M, D, 0, x_out,
-                                     (dt == F32 || lastl) ? nullptr : xT, st));
-        } else if (lastl) {
-            Prof pr(e, st, "layernorm:enc", 0, gM * D * 8);
-            HIP_TRY(launch_layernorm(dt, (const float*)tmp2, (const float*)e->eln_g.p, (const float*)e->eln_b.p, M, D, 0, x_out,
-                                     nullptr, st));
+            HIP_TRY(launch_layernorm(dt, (const float*)tmp1, (const float*)Lw.ln2g.p, (const float*)Lw.ln2b.p, M, D, 0, x_next,
+                                     h16, st, sink.acc(si_next, 2)));
+            a16_cur = h16;
         }
-        if (!e->layer_events.empty()) HIP_TRY(hipEventRecord(e->layer_events[l + 1], st));
+        HIP_TRY(sink.done(si_next));
+        x_cur = x_next;
+        si_cur = si_next;
+    }
+    const float* enc_out = x_cur;  // what the DistilHuBERT heads read
+    const void* enc_out16 = a16_cur;
+    if (prel) {
+        // encoder.layer_norm on the last residual stream (wav2vec2_model.py:3049-3050): the encoder output
+        const int si_fin = si_hidden(NL);
+        float* y = sink.slot32(si_fin) ? sink.slot32(si_fin) : other(x_cur);
+        void* y16 = dt == F32 ? nullptr : (sink.slot16(si_fin) ? sink.slot16(si_fin) : xT);
+        // featurize: this LayerNorm adds the term of its output (hidden list) or of its input (fairseq_layers / distiller)
+        LnAcc fa = sink.wanted(si_fin) ? sink.acc(si_fin, 2) : sink.acc(si_cur, 1);
+        Prof pr(e, st, "layernorm:enc", 0, gM * D * 8);
+        HIP_TRY(launch_layernorm(dt, x_cur, (const float*)e->eln_g.p, (const float*)e->eln_b.p, M, D, 0, y, y16, st, fa));
+        HIP_TRY(sink.done(si_fin));
+        enc_out = y;
+        enc_out16 = y16;
+    }
+    if (NH) {
+        // DistilHuBERT prediction heads (distiller/model.py:155-161,245-258): Linear(D, NH*D) + GELU, then per head k
+        // the (D x D) slice of SplitLinear on columns [k*D, (k+1)*D) of the intermediate
+        {
+            GemmParams g{};
+            g.A = dt == F32 ? (const void*)enc_out : enc_out16;
+            g.lda = D;
+            g.W = e->head_w1.p;
+            g.W_x3 = e->head_w13.p;
+            g.bias = (const float*)e->head_b1.p;
+            g.M = (int)M;
+            g.N = NH * D;
+            g.K = D;
+            g.batches = 1;
+            g.act = 1;
+            g.ldo = (long)NH * D;
+            if (dt == F32) g.out32 = (float*)hbuf; else g.out16 = hbuf;
+            Prof pr(e, st, "gemm:head1", 2.0 * gM * NH * D * D, (gM * D + (double)NH * D * D + gM * NH * D) * es);
+            HIP_TRY(launch_gemm(dt, g, st));
+        }
+        for (int k = 0; k < NH; ++k) {
+            const int si = 1 + NL + k;
+            float* dst = sink.slot32(si) ? sink.slot32(si) : (float*)tmp1;
+            GemmParams g{};
+            g.A = (const char*)hbuf + (size_t)k * D * es;
+            g.lda = (long)NH * D;
+            g.W = (const char*)e->head_w2.p + (size_t)k * D * D * es;
+            g.W_x3 = e->head_w23.p ? (const char*)e->head_w23.p + (size_t)k * D * D * 4 : nullptr;
+            g.bias = (const float*)e->head_b2.p + (long)k * D;
+            g.M = (int)M;
+            g.N = D;
+            g.K = D;
+            g.batches = 1;
+            g.ldo = D;
+            g.out32 = dst;
+            g.out16 = sink.slot16(si);
+            {
+                Prof pr(e, st, "gemm:head2", 2.0 * gM * D * D, (gM * D + (double)D * D) * es + gM * D * 4);
+                HIP_TRY(launch_gemm(dt, g, st));
+            }
+            HIP_TRY(sink.emit(si, dst, false));
+            HIP_TRY(sink.done(si));
+        }
     }
     return 0;
 }
@@ -952,10 +1210,38 @@ int forward_impl(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
 
 extern "C" {
 
+static int parse_opts(s3enc_handle h, const s3enc_forward_opts* o, FwdOpts& fo) {
+    if (!o) return 0;
+    fo.selection = o->selection;
+    fo.out_dtype = o->out_dtype;
+    fo.featurize = o->featurize != 0;
+    fo.feat_norm = o->feat_normalize != 0;
+    fo.w = o->feat_w;
+    if (fo.out_dtype < 0 || fo.out_dtype > 2) return fail("s3enc_forward_ex: out_dtype must be S3ENC_F32 / BF16 / F16");
+    return 0;
+}
+
 int s3enc_forward(s3enc_handle h, const float* const* wavs, const int64_t* lengths, int32_t B, int64_t n_max, float* out,
                   int64_t layer_stride, void* stream) {
     if (!h || !wavs || !lengths) return fail("s3enc_forward: null argument");
-    return forward_impl(h, wavs, lengths, B, n_max, out, layer_stride, (hipStream_t)stream);
+    return forward_impl(h, wavs, lengths, B, n_max, FwdOpts(), out, layer_stride, (hipStream_t)stream);
+}
+
+int s3enc_forward_ex(s3enc_handle h, const float* const* wavs, const int64_t* lengths, int32_t B, int64_t n_max,
+                     const s3enc_forward_opts* opts, void* out, int64_t layer_stride, void* stream) {
+    if (!h || !wavs || !lengths) return fail("s3enc_forward_ex: null argument");
+    FwdOpts fo;
+    if (parse_opts(h, opts, fo)) return 1;
+    return forward_impl(h, wavs, lengths, B, n_max, fo, out, layer_stride, (hipStream_t)stream);
+}
+
+int s3enc_num_states(s3enc_handle h, int32_t selection, int32_t* n) {
+    if (!h || !n) return fail("s3enc_num_states: null argument");
+    if (selection < 0 || selection > 2) return fail("s3enc_num_states: unknown selection");
+    if (h->cfg.family == S3ENC_DISTILLER && selection != S3ENC_SEL_HIDDEN)
+        return fail("s3enc_num_states: DistilHuBERT has one selection (its hidden_states list)");
+    *n = num_states(h->cfg, selection);
+    return 0;
 }
 
 int s3enc_forward_padded(s3enc_handle h, const float* pcm, int64_t row_stride, const int64_t* lengths, int32_t B, int64_t n_max,
@@ -967,7 +1253,7 @@ int s3enc_forward_padded(s3enc_handle h, const float* pcm, int64_t row_stride, c
         if (lengths[b] > row_stride) return fail("s3enc_forward_padded: length exceeds row_stride");
         ptrs[b] = pcm + (long)b * row_stride;
     }
-    return forward_impl(h, ptrs.data(), lengths, B, n_max, out, layer_stride, (hipStream_t)stream);
+    return forward_impl(h, ptrs.data(), lengths, B, n_max, FwdOpts(), out, layer_stride, (hipStream_t)stream);
 }
 
 int s3enc_set_layer_events(s3enc_handle h, void* const* events, int32_t n) {
@@ -976,7 +1262,8 @@ int s3enc_set_layer_events(s3enc_handle h, void* const* events, int32_t n) {
         h->layer_events.clear();
         return 0;
     }
-    if (!events || n != h->cfg.encoder_layers + 1) return fail("s3enc_set_layer_events: need encoder_layers+1 events");
+    if (!events || n < h->cfg.encoder_layers || n > h->cfg.encoder_layers + 1 + h->cfg.pred_heads)
+        return fail("s3enc_set_layer_events: pass one event per state of the selection the forwards will use");
     h->layer_events.assign((hipEvent_t const*)events, (hipEvent_t const*)events + n);
     return 0;
 }
@@ -988,11 +1275,11 @@ int s3enc_profile_enable(s3enc_handle h, int32_t on) {
 }
 int s3enc_profile_reset(s3enc_handle h) {
     if (!h) return fail("null handle");
-    HIP_TRY(hipSetDevice(h->device));
+    DeviceGuard dg(h->device);
     HIP_TRY(hipDeviceSynchronize());
     for (auto& r : h->recs) {
-        (void)hipEventDestroy(r.a);
-        (void)hipEventDestroy(r.b);
+        h->ev_pool.push_back(r.a);
+        h->ev_pool.push_back(r.b);
     }
     h->recs.clear();
     h->kinds.clear();
@@ -1003,7 +1290,7 @@ int s3enc_profile_reset(s3enc_handle h) {
 }
 int s3enc_profile_read(s3enc_handle h, s3enc_profile_entry* entries, int32_t max_entries, int32_t* n_entries) {
     if (!h || !entries || !n_entries) return fail("s3enc_profile_read: null argument");
-    HIP_TRY(hipSetDevice(h->device));
+    DeviceGuard dg(h->device);
     HIP_TRY(hipDeviceSynchronize());
     std::vector<double> ms(h->kinds.size(), 0.0);
     for (auto& r : h->recs) {
@@ -1031,7 +1318,7 @@ int s3enc_debug_tap(s3enc_handle h, const char* name, float* host_out, int64_t m
     *n_elems = it->second.elems;
     if (!host_out) return 0;
     if (max_elems < it->second.elems) return fail("s3enc_debug_tap: buffer too small");
-    HIP_TRY(hipSetDevice(h->device));
+    DeviceGuard dg(h->device);
     HIP_TRY(hipDeviceSynchronize());
     if (it->second.dtype == F32) {
         HIP_TRY(hipMemcpy(host_out, it->second.p, (size_t)it->second.elems * 4, hipMemcpyDeviceToHost));
@@ -1102,7 +1389,8 @@ int s3enc_op_layernorm(int32_t dtype, const float* x, const float* gamma, const 
 }
 
 int s3enc_op_attention(int32_t dtype, const void* qkv, void* out, const int32_t* valid, int32_t B, int32_t T, int32_t H,
-                       const float* bias_table, const float* gate, void* stream) {
+                       const float* bias_table, int32_t table_R, const float* gate, void* stream) {
+    if (bias_table && (table_R < 0 || T > 6000)) return fail("s3enc_op_attention: bad table_R / T > 6000 with a bias table");
     AttnParams a{};
     a.qkv = qkv;
     a.out = out;
@@ -1111,8 +1399,71 @@ int s3enc_op_attention(int32_t dtype, const void* qkv, void* out, const int32_t*
     a.T = T;
     a.H = H;
     a.bias_table = bias_table;
+    a.table_R = table_R;
     a.gate = gate;
     HIP_TRY(launch_attention(dtype, a, (hipStream_t)stream));
+    return 0;
+}
+
+int s3enc_op_conv0(int32_t dtype, const float* const* wavs, const int64_t* lengths, int32_t B, int64_t n_max, int32_t normalize,
+                   const float* w0, const float* bias, const float* gn_gamma, const float* gn_beta, const float* ln_gamma,
+                   const float* ln_beta, int32_t C, int32_t stride, void* out, void* stream) {
+    if (!wavs || !lengths || !w0 || !out) return fail("s3enc_op_conv0: null argument");
+    if (B <= 0 || C <= 0 || (C % 32) || C > 1024 || stride <= 0) return fail("s3enc_op_conv0: bad shape");
+    if (dtype < 0 || dtype > 2) return fail("s3enc_op_conv0: dtype must be S3ENC_F32 / BF16 / F16");
+    if ((gn_gamma != nullptr) == (ln_gamma != nullptr)) return fail("s3enc_op_conv0: pass exactly one of gn_gamma / ln_gamma");
+    const int k0 = 10;
+    long nm = 0;
+    for (int b = 0; b < B; ++b) nm = lengths[b] > nm ? lengths[b] : nm;
+    if (n_max > 0 && n_max < nm) return fail("s3enc_op_conv0: n_max is smaller than the longest utterance");
+    if (n_max > 0) nm = n_max;
+    if (nm < k0) return fail("s3enc_op_conv0: input shorter than the kernel");
+    const long L0 = (nm - k0) / stride + 1;
+    hipStream_t st = (hipStream_t)stream;
+    // scratch: table (ptrs, lens), per-utterance norm, per-(b, c) GroupNorm affine, reduction partials
+    const size_t tbl = (size_t)B * 16, part = stats_partial_elems(B, nm);
+    DevBuf buf;
+    Bump sz(nullptr);
+    sz.take(tbl);
+    sz.take((size_t)B * sizeof(float2));
+    sz.take((size_t)B * C * sizeof(float2));
+    sz.take(part * 8);
+    HIP_TRY(buf.ensure(sz.off + 256));
+    Bump bb(buf.p);
+    char* d_tbl = (char*)bb.take(tbl);
+    float2* d_norm = (float2*)bb.take((size_t)B * sizeof(float2));
+    float2* d_gn = (float2*)bb.take((size_t)B * C * sizeof(float2));
+    double* d_part = (double*)bb.take(part * 8);
+    std::vector<char> host(tbl);
+    memcpy(host.data(), wavs, (size_t)B * 8);
+    for (int b = 0; b < B; ++b) ((long*)(host.data() + (size_t)B * 8))[b] = (long)lengths[b];
+    HIP_TRY(hipMemcpy(d_tbl, host.data(), tbl, hipMemcpyHostToDevice));
+    WavTable wt{(const float* const*)d_tbl, (const long*)(d_tbl + (size_t)B * 8), B, nm};
+    HIP_TRY(launch_wav_norm_stats(wt, normalize, d_part, d_norm, st));
+    if (gn_gamma) HIP_TRY(launch_gn_stats(wt, d_norm, w0, gn_gamma, gn_beta, C, k0, stride, L0, d_part, nullptr, d_gn, st));
+    Conv0Params p{};
+    p.wav = wt;
+    p.norm = d_norm;
+    p.w0 = w0;
+    p.bias = bias;
+    p.gn = gn_gamma ? d_gn : nullptr;
+    p.ln_g = ln_gamma;
+    p.ln_b = ln_beta;
+    p.C = C;
+    p.k0 = k0;
+    p.s0 = stride;
+    p.L0 = L0;
+    p.out = out;
+    HIP_TRY(launch_conv0(dtype, p, st));
+    HIP_TRY(hipStreamSynchronize(st));  // the scratch is freed on return
+    return 0;
+}
+
+int s3enc_op_wavlm_gate(const float* x, const float* grep_w, const float* grep_b, const float* grep_a, int32_t B, int32_t T,
+                        int32_t H, float* gate, void* stream) {
+    if (!x || !grep_w || !grep_b || !grep_a || !gate) return fail("s3enc_op_wavlm_gate: null argument");
+    if (B <= 0 || T <= 0 || H <= 0) return fail("s3enc_op_wavlm_gate: bad shape");
+    HIP_TRY(launch_wavlm_gate(x, grep_w, grep_b, grep_a, B, T, H, gate, (hipStream_t)stream));
     return 0;
 }
 
@@ -1153,16 +1504,17 @@ int s3enc_weighted_sum(const float* hs, int64_t layer_stride, int32_t L, const f
     return 0;
 }
 
+int64_t s3enc_weighted_sum_backward_scratch(int64_t rows, int32_t L) {
+    return rows > 0 && L > 0 ? (int64_t)weighted_sum_bwd_blocks(rows) * L : 0;
+}
+
 int s3enc_weighted_sum_backward(const float* hs, int64_t layer_stride, int32_t L, int32_t normalize, int64_t rows, int32_t D,
-                                const float* grad_out, float* grad_w, void* stream) {
-    if (!hs || !grad_out || !grad_w) return fail("s3enc_weighted_sum_backward: null argument");
+                                const float* grad_out, float* grad_w, double* scratch, void* stream) {
+    if (!hs || !grad_out || !grad_w || !scratch) return fail("s3enc_weighted_sum_backward: null argument");
     if (L <= 0 || L > S3_WS_MAX_LAYERS) return fail("s3enc_weighted_sum_backward: 1..32 layers");
     if (D <= 0 || (D & 3) || D > 2048) return fail("s3enc_weighted_sum_backward: D must be a multiple of 4, <= 2048");
     if (rows <= 0) return fail("s3enc_weighted_sum_backward: no rows");
-    DevBuf part;
-    HIP_TRY(part.ensure((size_t)weighted_sum_bwd_blocks(rows) * L * sizeof(double)));
-    HIP_TRY(launch_weighted_sum_bwd(hs, layer_stride, L, normalize, rows, D, grad_out, (double*)part.p, grad_w, (hipStream_t)stream));
-    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    HIP_TRY(launch_weighted_sum_bwd(hs, layer_stride, L, normalize, rows, D, grad_out, scratch, grad_w, (hipStream_t)stream));
     return 0;
 }
 

@@ -80,8 +80,19 @@ struct Conv0Params {
 hipError_t launch_conv0(int dtype, const Conv0Params& p, hipStream_t s);
 
 // ---- norm.hip -------------------------------------------------------------------------------------------
+// Featurizer term fused into a row kernel: acc[row] (+)= w * state_row  (norm: w * layer_norm(state_row), no affine)
+struct LnAcc {
+    float* acc = nullptr;  // (rows, C) fp32
+    float w = 0.f;
+    int mode = 0;  // 0 none; 1: the kernel's INPUT row is the state; 2: its OUTPUT row is
+    int norm = 0;
+    int init = 0;  // first term: write instead of add
+};
 hipError_t launch_layernorm(int dtype, const float* x, const float* gamma, const float* beta, long rows, int C, int act,
-                            float* out32, void* out16, hipStream_t s);
+                            float* out32, void* out16, hipStream_t s, const LnAcc& fa = LnAcc());
+// a state produced by a non-LayerNorm kernel: its 16-bit copy (out16, dtype BF16 / F16) and / or its Featurizer term
+hipError_t launch_emit_state(int dtype, const float* x, long rows, int C, void* out16, const LnAcc& fa, hipStream_t s);
+hipError_t launch_add(const float* a, const float* b, float* out, long n, hipStream_t s);  // out = a + b, n % 4 == 0
 
 // ---- attention.hip ----------------------------------------------------------------------------------------
 struct AttnParams {
@@ -89,7 +100,8 @@ struct AttnParams {
     void* out;        // (B*T, D)
     const int* valid; // [B] keys >= valid[b] are masked
     int B, T, H;
-    const float* bias_table;  // WavLM: [H][2T-1] or null
+    const float* bias_table;  // WavLM: [H][2R+1], entry (h, clamp(key - query, -R, R) + R), or null
+    int table_R = 0;
     const float* gate;        // WavLM: [B][H][T] or null (then gate = 1)
 };
 hipError_t launch_attention(int dtype, const AttnParams& p, hipStream_t s);

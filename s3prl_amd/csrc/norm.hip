@@ -4,6 +4,9 @@
 // Serves: LayerNorm(512) before post_extract_proj (hubert_model.py:482-483), encoder.layer_norm
 // (wav2vec2_model.py:3049-3050,3069-3070), self_attn_layer_norm / final_layer_norm (:3274-3320) and the
 // per-conv Fp32LayerNorm + GELU of layer_norm-mode extractors (:2887-2897).
+// Featurizer epilogue (nn/upstream.py:312-328): with an LnAcc the same pass also adds  w * state  (or
+// w * layer_norm(state), no affine) of the row it already holds in registers — its input (a pre-LN residual
+// stream that IS a hidden state) or its output (a post-LN hidden state) — into the (rows, C) weighted-sum block.
 #include "kernels.h"
 
 namespace s3 {
@@ -12,7 +15,7 @@ namespace {
 template <typename T, int NCH>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, long rows, int C, int act,
-                                                        float* out32, void* out16) {
+                                                        float* out32, void* out16, LnAcc fa) {
     typedef typename Cvt<T>::store_t store_t;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -39,6 +42,22 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
         }
     }
     const float rs = rsqrtf(wave_sum(q) * invC + LN_EPS);
+    if (fa.mode == 1) {  // the INPUT row is a state: acc (+)= w * x, or w * (x - mu) * rs with the statistics above
+        const float a = fa.norm ? fa.w * rs : fa.w, c0 = fa.norm ? -mu * a : 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int ch = lane + 64 * i;
+            if (ch >= nch) continue;
+            float4* dst = (float4*)(fa.acc + row * C + 4 * ch);
+            float4 t = fa.init ? make_float4(0.f, 0.f, 0.f, 0.f) : *dst;
+            t.x += fmaf(v[i].x, a, c0);
+            t.y += fmaf(v[i].y, a, c0);
+            t.z += fmaf(v[i].z, a, c0);
+            t.w += fmaf(v[i].w, a, c0);
+            *dst = t;
+        }
+    }
+    float ys = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int ch = lane + 64 * i;
@@ -69,15 +88,120 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
                 *(ushort4*)((u16*)out16 + row * C + 4 * ch) = h;
             }
         }
+        if (fa.mode == 2) {  // keep y in the registers of x for the accumulate pass below
+            v[i] = y;
+            ys += (y.x + y.y) + (y.z + y.w);
+        }
     }
+    if (fa.mode == 2) {  // the OUTPUT row is a state
+        float a = fa.w, c0 = 0.f;
+        if (fa.norm) {
+            const float ym = wave_sum(ys) * invC;
+            float yq = 0.f;
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int ch = lane + 64 * i;
+                if (ch < nch) {
+                    const float a0 = v[i].x - ym, b0 = v[i].y - ym, c1 = v[i].z - ym, d0 = v[i].w - ym;
+                    yq += (a0 * a0 + b0 * b0) + (c1 * c1 + d0 * d0);
+                }
+            }
+            a = fa.w * rsqrtf(wave_sum(yq) * invC + LN_EPS);
+            c0 = -ym * a;
+        }
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int ch = lane + 64 * i;
+            if (ch >= nch) continue;
+            float4* dst = (float4*)(fa.acc + row * C + 4 * ch);
+            float4 t = fa.init ? make_float4(0.f, 0.f, 0.f, 0.f) : *dst;
+            t.x += fmaf(v[i].x, a, c0);
+            t.y += fmaf(v[i].y, a, c0);
+            t.z += fmaf(v[i].z, a, c0);
+            t.w += fmaf(v[i].w, a, c0);
+            *dst = t;
+        }
+    }
+}
+
+// Standalone state emission for producers that are not a LayerNorm: a row of a state -> its 16-bit copy in the caller's
+// slab and / or its term of the Featurizer sum.
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void emit_kernel(const float* x, long rows, int C, void* out16, LnAcc fa) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const int nch = C >> 2;
+    const float* xr = x + row * C;
+    float4 v[NCH];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int ch = lane + 64 * i;
+        v[i] = ch < nch ? *(const float4*)(xr + 4 * ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    if (out16) {
+        if constexpr (sizeof(typename Cvt<T>::store_t) == 2) {
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int ch = lane + 64 * i;
+                if (ch >= nch) continue;
+                ushort4 h;
+                h.x = Cvt<T>::to(v[i].x);
+                h.y = Cvt<T>::to(v[i].y);
+                h.z = Cvt<T>::to(v[i].z);
+                h.w = Cvt<T>::to(v[i].w);
+                *(ushort4*)((u16*)out16 + row * C + 4 * ch) = h;
+            }
+        }
+    }
+    if (fa.mode) {
+        float a = fa.w, c0 = 0.f;
+        if (fa.norm) {
+            const float invC = 1.f / (float)C;
+            const float mu = wave_sum(s) * invC;
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int ch = lane + 64 * i;
+                if (ch < nch) {
+                    const float a0 = v[i].x - mu, b0 = v[i].y - mu, c1 = v[i].z - mu, d0 = v[i].w - mu;
+                    q += (a0 * a0 + b0 * b0) + (c1 * c1 + d0 * d0);
+                }
+            }
+            a = fa.w * rsqrtf(wave_sum(q) * invC + LN_EPS);
+            c0 = -mu * a;
+        }
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int ch = lane + 64 * i;
+            if (ch >= nch) continue;
+            float4* dst = (float4*)(fa.acc + row * C + 4 * ch);
+            float4 t = fa.init ? make_float4(0.f, 0.f, 0.f, 0.f) : *dst;
+            t.x += fmaf(v[i].x, a, c0);
+            t.y += fmaf(v[i].y, a, c0);
+            t.z += fmaf(v[i].z, a, c0);
+            t.w += fmaf(v[i].w, a, c0);
+            *dst = t;
+        }
+    }
+}
+
+// out = a + b (fp32, n4 float4): re-applies the residual after a fc2 GEMM that exported its pre-residual output
+__global__ __launch_bounds__(256) void add_kernel(const float4* a, const float4* b, float4* out, long n4) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const float4 x = a[i], y = b[i];
+    out[i] = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
 }
 
 template <typename T>
 hipError_t ln_dispatch(const float* x, const float* gamma, const float* beta, long rows, int C, int act, float* out32,
-                       void* out16, hipStream_t s) {
+                       void* out16, const LnAcc& fa, hipStream_t s) {
     const int per_lane = ((C >> 2) + 63) / 64;
     dim3 grid((unsigned)((rows + 3) / 4)), block(256);
-#define S3_LN(N) hipLaunchKernelGGL((layernorm_kernel<T, N>), grid, block, 0, s, x, gamma, beta, rows, C, act, out32, out16)
+#define S3_LN(N) hipLaunchKernelGGL((layernorm_kernel<T, N>), grid, block, 0, s, x, gamma, beta, rows, C, act, out32, out16, fa)
     if (per_lane <= 1) S3_LN(1);
     else if (per_lane == 2) S3_LN(2);
     else if (per_lane == 3) S3_LN(3);
@@ -90,15 +214,49 @@ hipError_t ln_dispatch(const float* x, const float* gamma, const float* beta, lo
 }  // namespace
 
 hipError_t launch_layernorm(int dtype, const float* x, const float* gamma, const float* beta, long rows, int C, int act,
-                            float* out32, void* out16, hipStream_t s) {
+                            float* out32, void* out16, hipStream_t s, const LnAcc& fa) {
     if (rows <= 0) return hipSuccess;
     if ((C & 3) || C > 2048) return hipErrorInvalidValue;
     switch (dtype) {
-        case F32: return ln_dispatch<float>(x, gamma, beta, rows, C, act, out32, out16, s);
-        case BF16: return ln_dispatch<bf16_tag>(x, gamma, beta, rows, C, act, out32, out16, s);
-        case F16: return ln_dispatch<f16_tag>(x, gamma, beta, rows, C, act, out32, out16, s);
+        case F32: return ln_dispatch<float>(x, gamma, beta, rows, C, act, out32, out16, fa, s);
+        case BF16: return ln_dispatch<bf16_tag>(x, gamma, beta, rows, C, act, out32, out16, fa, s);
+        case F16: return ln_dispatch<f16_tag>(x, gamma, beta, rows, C, act, out32, out16, fa, s);
     }
     return hipErrorInvalidValue;
+}
+
+template <typename T>
+static hipError_t emit_dispatch(const float* x, long rows, int C, void* out16, const LnAcc& fa, hipStream_t s) {
+    const int per_lane = ((C >> 2) + 63) / 64;
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+#define S3_EM(N) hipLaunchKernelGGL((emit_kernel<T, N>), grid, block, 0, s, x, rows, C, out16, fa)
+    if (per_lane <= 1) S3_EM(1);
+    else if (per_lane == 2) S3_EM(2);
+    else if (per_lane == 3) S3_EM(3);
+    else if (per_lane == 4) S3_EM(4);
+    else S3_EM(8);
+#undef S3_EM
+    return hipGetLastError();
+}
+
+hipError_t launch_emit_state(int dtype, const float* x, long rows, int C, void* out16, const LnAcc& fa, hipStream_t s) {
+    if (rows <= 0 || (!out16 && !fa.mode)) return hipSuccess;
+    if ((C & 3) || C > 2048) return hipErrorInvalidValue;
+    switch (dtype) {
+        case F32: return emit_dispatch<float>(x, rows, C, nullptr, fa, s);
+        case BF16: return emit_dispatch<bf16_tag>(x, rows, C, out16, fa, s);
+        case F16: return emit_dispatch<f16_tag>(x, rows, C, out16, fa, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_add(const float* a, const float* b, float* out, long n, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    if (n & 3) return hipErrorInvalidValue;
+    const long n4 = n >> 2;
+    hipLaunchKernelGGL(add_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, (const float4*)a, (const float4*)b,
+                       (float4*)out, n4);
+    return hipGetLastError();
 }
 
 }  // namespace s3

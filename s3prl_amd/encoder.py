@@ -41,7 +41,8 @@ class HipEncoder:
             for j, s in enumerate(shape):
                 tensors[i].shape[j] = int(s)
         h = C.c_void_p()
-        _lib.check(self._lib.s3enc_create(C.byref(ccfg), tensors, len(weights), self.device, C.byref(h)), "s3enc_create")
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.s3enc_create(C.byref(ccfg), tensors, len(weights), self.device, C.byref(h)), "s3enc_create")
         self._h = h
         self.num_layers = cfg.encoder_layers
         self.embed_dim = cfg.encoder_embed_dim
@@ -73,10 +74,14 @@ class HipEncoder:
         _lib.check(self._lib.s3enc_downsample_rate(self._h, C.byref(r)))
         return r.value
 
+    def num_states(self, selection=None) -> int:
+        """Entries of the states list under ``selection`` (None / "fairseq_layers" / "fairseq_layers_before_residual")."""
+        n = C.c_int32()
+        _lib.check(self._lib.s3enc_num_states(self._h, _lib.SELECTIONS[selection], C.byref(n)), "s3enc_num_states")
+        return n.value
+
     # ---- forward ----
-    def forward(self, wavs: Sequence["torch.Tensor"], n_max: Optional[int] = None, out: Optional["torch.Tensor"] = None):
-        """wavs: list of 1-D fp32 CUDA tensors.  Returns a (NL+1, B, T, D) fp32 CUDA tensor; ``[l]`` is
-        ``hidden_states[l]``.  ``n_max``: pad-to length of the GLOBAL batch (data-parallel shards)."""
+    def _prepare(self, wavs, n_max):
         import torch
 
         B = len(wavs)
@@ -95,29 +100,79 @@ class HipEncoder:
         T = self.num_frames(nm)
         if T < 1:
             raise ValueError(f"input of {nm} samples is shorter than the receptive field of the conv stack")
-        NL, D = self.num_layers, self.embed_dim
+        return dev, held, lengths, nm, T
+
+    def forward(self, wavs: Sequence["torch.Tensor"], n_max: Optional[int] = None, out: Optional["torch.Tensor"] = None,
+                selection: Optional[str] = None, out_dtype: Optional[str] = None):
+        """wavs: list of 1-D fp32 CUDA tensors.  Returns a (NS, B, T, D) CUDA tensor; ``[i]`` is state i of
+        ``selection`` (default: ``hidden_states``).  ``n_max``: pad-to length of the GLOBAL batch (data-parallel
+        shards).  ``out_dtype``: None / "fp32", or the encoder's own 16-bit compute dtype ("bf16" / "fp16") to get
+        the states as 16-bit tensors (half the bytes to write and to all-gather)."""
+        import torch
+
+        dev, held, lengths, nm, T = self._prepare(wavs, n_max)
+        B, D = len(held), self.embed_dim
+        NS = self.num_states(selection)
+        tdt, code = torch.float32, _lib.F32
+        if out_dtype not in (None, "fp32", "f32", "float32"):
+            code = _lib.DTYPES[out_dtype]
+            if code != _lib.DTYPES[self.dtype] or code not in (_lib.BF16, _lib.F16):
+                raise ValueError(f"out_dtype {out_dtype!r}: only fp32 or the encoder's own 16-bit compute dtype ({self.dtype})")
+            tdt = torch.bfloat16 if code == _lib.BF16 else torch.float16
         if out is None:
-            out = torch.empty((NL + 1, B, T, D), dtype=torch.float32, device=dev)
+            out = torch.empty((NS, B, T, D), dtype=tdt, device=dev)
         else:
-            assert out.is_contiguous() and out.dtype == torch.float32 and tuple(out.shape) == (NL + 1, B, T, D)
+            assert out.is_contiguous() and out.dtype == tdt and tuple(out.shape) == (NS, B, T, D)
         ptrs = (C.c_void_p * B)(*[w.data_ptr() for w in held])
         lens = (C.c_int64 * B)(*lengths)
+        opts = _lib.S3ForwardOpts(_lib.SELECTIONS[selection], code, 0, 0, None)
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
-            rc = self._lib.s3enc_forward(self._h, ptrs, lens, B, nm, C.c_void_p(out.data_ptr()), B * T * D,
-                                         C.c_void_p(stream))
+            rc = self._lib.s3enc_forward_ex(self._h, ptrs, lens, B, nm, C.byref(opts), C.c_void_p(out.data_ptr()), B * T * D,
+                                            C.c_void_p(stream))
         _lib.check(rc, "s3enc_forward")
         return out
 
+    def forward_featurized(self, wavs: Sequence["torch.Tensor"], weights: Sequence[float], normalize: bool = False,
+                           n_max: Optional[int] = None, out: Optional["torch.Tensor"] = None,
+                           selection: Optional[str] = None):
+        """The Featurizer's weighted sum as the encoder's epilogue: returns ONLY
+        ``sum_i weights[i] * (layer_norm(state_i) if normalize else state_i)`` as one fp32 (B, T, D) tensor — the
+        states never leave the workspace, so the encoder writes 1/(NL+1) of the bytes and a data-parallel exchange
+        moves one layer.  ``weights``: one float per state (softmax already applied; 0 = layer not selected)."""
+        import torch
+
+        dev, held, lengths, nm, T = self._prepare(wavs, n_max)
+        B, D = len(held), self.embed_dim
+        NS = self.num_states(selection)
+        w = [float(x) for x in weights]
+        if len(w) != NS:
+            raise ValueError(f"need one weight per state ({NS}), got {len(w)}")
+        if out is None:
+            out = torch.empty((B, T, D), dtype=torch.float32, device=dev)
+        else:
+            assert out.is_contiguous() and out.dtype == torch.float32 and tuple(out.shape) == (B, T, D)
+        wp = (C.c_float * NS)(*w)
+        ptrs = (C.c_void_p * B)(*[x.data_ptr() for x in held])
+        lens = (C.c_int64 * B)(*lengths)
+        opts = _lib.S3ForwardOpts(_lib.SELECTIONS[selection], _lib.F32, 1, int(bool(normalize)), wp)
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            rc = self._lib.s3enc_forward_ex(self._h, ptrs, lens, B, nm, C.byref(opts), C.c_void_p(out.data_ptr()), 0,
+                                            C.c_void_p(stream))
+        _lib.check(rc, "s3enc_forward (featurize)")
+        return out
+
     def layer_events(self):
-        """NL+1 CUDA events, recorded by every following forward when hidden_states[l] is final (created once)."""
+        """One CUDA event per state of the default selection, recorded by every following forward when state l is
+        final (created once)."""
         import torch
 
         if getattr(self, "_events", None) is None:
             dev = torch.device("cuda", self.device)
             evs = []
             with torch.cuda.device(dev):
-                for _ in range(self.num_layers + 1):
+                for _ in range(self.num_states()):
                     ev = torch.cuda.Event(enable_timing=False)
                     ev.record(torch.cuda.current_stream(dev))  # torch creates the hipEvent_t lazily: force it
                     evs.append(ev)

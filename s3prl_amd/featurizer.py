@@ -23,13 +23,16 @@ from . import _lib
 
 
 def _as_slab(all_hs: List[torch.Tensor]):
-    """(base tensor, layer stride in elements) if the layers are equally spaced views of one allocation, else a stack."""
+    """(base tensor, layer stride in elements) if the layers are equally spaced row-major views of one allocation
+    (what our experts return), else a row-major stack — the reference experts' hooks return transposed views of
+    (T, B, D) memory (``input[0].transpose(0, 1)``, hubert/expert.py:39), which are dense but NOT row-major."""
     h0 = all_hs[0]
     if len(all_hs) > 1 and all(h.is_contiguous() and h.shape == h0.shape and h.dtype == torch.float32 for h in all_hs):
         step = (all_hs[1].data_ptr() - h0.data_ptr()) // 4
-        if step >= h0.numel() and all((h.data_ptr() - h0.data_ptr()) == 4 * step * i for i, h in enumerate(all_hs)):
+        if step >= h0.numel() and step % 4 == 0 and h0.data_ptr() % 16 == 0 and \
+                all((h.data_ptr() - h0.data_ptr()) == 4 * step * i for i, h in enumerate(all_hs)):
             return h0, step, None
-    stacked = torch.stack([h.float() for h in all_hs], dim=0).contiguous()
+    stacked = torch.stack([h.float() for h in all_hs], dim=0).contiguous()  # (L, B, T, D) row-major
     return stacked[0], stacked[0].numel(), stacked
 
 
@@ -43,7 +46,7 @@ class _WeightedSum(torch.autograd.Function):
         base, step, keep = _as_slab(list(all_hs))
         L, D = len(all_hs), h0.shape[-1]
         rows = h0.numel() // D
-        out = torch.empty_like(h0, dtype=torch.float32)
+        out = torch.empty(h0.shape, dtype=torch.float32, device=h0.device)  # row-major, whatever h0's strides are
         w = norm_weights.detach().float().cpu().contiguous()
         wp = (C.c_float * L)(*w.tolist())
         with torch.cuda.device(h0.device):
@@ -60,11 +63,14 @@ class _WeightedSum(torch.autograd.Function):
         lib = _lib.load()
         g = grad_out.contiguous().float()
         gw = torch.empty(ctx.L, dtype=torch.float32, device=g.device)
+        # reduction partials come from torch's caching allocator: stream-ordered reuse, no hipMalloc / sync per step
+        scratch = torch.empty(int(lib.s3enc_weighted_sum_backward_scratch(ctx.rows, ctx.L)), dtype=torch.float64, device=g.device)
         with torch.cuda.device(g.device):
             stream = torch.cuda.current_stream(g.device).cuda_stream
             _lib.check(lib.s3enc_weighted_sum_backward(C.c_void_p(ctx.base.data_ptr()), ctx.step, ctx.L, int(ctx.normalize),
                                                        ctx.rows, ctx.D, C.c_void_p(g.data_ptr()), C.c_void_p(gw.data_ptr()),
-                                                       C.c_void_p(stream)), "s3enc_weighted_sum_backward")
+                                                       C.c_void_p(scratch.data_ptr()), C.c_void_p(stream)),
+                       "s3enc_weighted_sum_backward")
         return (gw.to(device=ctx.wdev, dtype=ctx.wdtype), None) + (None,) * ctx.L  # frozen upstream: no grad to the layers
 
 

@@ -7,6 +7,7 @@ from .upstream.hubert.hubconf import *  # noqa: F401,F403
 from .upstream.wav2vec2.hubconf import *  # noqa: F401,F403
 from .upstream.wavlm.hubconf import *  # noqa: F401,F403
 from .upstream.unispeech_sat.hubconf import *  # noqa: F401,F403
+from .upstream.distiller.hubconf import *  # noqa: F401,F403
 from .upstream.baseline.hubconf import *  # noqa: F401,F403
 
 
@@ -22,8 +23,11 @@ def options(only_registered_ckpt: bool = False):
     return sorted(names)
 
 
-def register_into_s3prl(prefix: str = "", override: bool = True):
-    """setattr our entries on ``s3prl.hub`` (``prefix="amd_"`` keeps the reference entries alongside)."""
+def register_into_s3prl(prefix: str = "", override: bool = False):
+    """setattr our entries on ``s3prl.hub``.  By default existing reference entries are left alone (only names the
+    reference does not define are added); ``prefix="amd_"`` installs every entry alongside the reference's;
+    ``override=True`` replaces the reference entries of the same name — note that the URL-backed ones (``hubert``,
+    ``wavlm_base_plus`` …) then need ``ckpt=`` because this build never downloads."""
     import importlib
 
     hub = importlib.import_module("s3prl.hub")

@@ -76,6 +76,16 @@ def featurize_data_parallel(encode_fn: Callable[[List[torch.Tensor], int], torch
     return out[:B]
 
 
+def featurized_data_parallel(expert, weights: Sequence[float], wavs: Sequence[torch.Tensor], normalize: bool = False,
+                             group=None) -> torch.Tensor:
+    """Data-parallel encode with the Featurizer's weighted sum computed INSIDE the encoder (``s3enc_forward_ex``
+    featurize epilogue): every rank produces only its shard's (Bs, T, D) weighted sum and ONE all-gather
+    reassembles the batch — the per-layer slab is neither written nor exchanged.  ``weights``: one float per layer
+    (softmax already applied).  Returns (B, T, D) fp32, identical on every rank, input order."""
+    return featurize_data_parallel(lambda mine, n_max: expert.encode_featurized(mine, weights, normalize, n_max=n_max),
+                                   lambda feat: feat, wavs, group)
+
+
 _COMM_STREAMS = {}
 
 

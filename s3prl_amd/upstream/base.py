@@ -1,4 +1,4 @@
-"""Shared body of the three ``UpstreamExpert`` mirrors.
+"""Shared body of the ``UpstreamExpert`` mirrors.
 
 Contract kept from the reference (upstream/example/expert.py:11-77, upstream/interfaces.py:100-131):
 
@@ -6,17 +6,20 @@ Contract kept from the reference (upstream/example/expert.py:11-77,
   and ignored;
 * ``forward(wavs: List[FloatTensor (n_i,)]) -> dict`` with ``"hidden_states"`` (tuple of NL+1 ``(B, T, D)`` fp32
   tensors on the wavs' device: the input of every Transformer layer, then the encoder output), plus
-  ``"last_hidden_state"`` and ``"hidden_state_{i}"`` exactly as ``UpstreamBase.__call__`` adds them.  Because the
-  dict is complete, this module registers NO hooks;
+  ``"_hidden_states_info"``, ``"last_hidden_state"`` and ``"hidden_state_{i}"`` exactly as ``UpstreamBase.__call__``
+  adds them (interfaces.py:119-129).  Because the dict is complete, this module registers NO hooks;
 * ``get_downsample_rates(key) -> 320``.
 
-The forward is inference-only (the HIP path has no backward): asking for gradients raises.
+The forward is inference-only (the HIP path has no backward): asking for gradients raises.  Waveforms on the CPU are
+copied to the current GPU, encoded there, and the states are returned on the waveforms' device (that is a transfer,
+not a fallback: without a GPU the call raises) — ``S3PRLUpstream.__init__`` probes every upstream with CPU pseudo
+waveforms (nn/upstream.py:124-126).
 """
 
 from __future__ import annotations
 
 import os
-from typing import Dict, List
+from typing import Dict, List, Optional
 
 import torch
 
@@ -48,8 +51,35 @@ class HipUpstreamExpert(torch.nn.Module):
         self.register_buffer("_device_probe", torch.zeros(1), persistent=False)
         return self
 
+    # ---- what S3PRLUpstream learns from a probe forward (nn/upstream.py:124-140), without running one ----
+    @property
+    def num_layers(self) -> int:
+        return self.cfg.num_hidden_states
+
+    @property
+    def hidden_sizes(self) -> List[int]:
+        return [self.cfg.encoder_embed_dim] * self.num_layers
+
     def get_downsample_rates(self, key: str = None) -> int:
         return self.cfg.downsample_rate
+
+    def _states_info(self, n: int):
+        """The hook identifiers ``UpstreamBase.__call__`` reports as ``_hidden_states_info`` (interfaces.py:125;
+        hubert/expert.py:36-43)."""
+        NL = self.cfg.encoder_layers
+        if n == NL + 1:
+            return tuple(f"self.model.encoder.layers[{i}]" for i in range(NL)) + ("self.model.encoder",)
+        return tuple(f"state_{i}" for i in range(n))
+
+    def _compute_device(self, wavs: List[torch.Tensor]) -> torch.device:
+        dev = wavs[0].device
+        if dev.type == "cuda":
+            return dev
+        if dev.type == "cpu" and torch.cuda.is_available():
+            return torch.device("cuda", torch.cuda.current_device())
+        raise RuntimeError(
+            "s3prl_amd runs the encoder on an MI355X only and no GPU is visible "
+            "(there is deliberately no CPU fallback — use the reference s3prl expert on CPU)")
 
     def _encoder_for(self, device: torch.device) -> HipEncoder:
         if device.type != "cuda":
@@ -61,16 +91,35 @@ class HipUpstreamExpert(torch.nn.Module):
             self._encoders[idx] = HipEncoder(self.cfg, self._weights, dtype=self.dtype, device=idx)
         return self._encoders[idx]
 
-    def encode(self, wavs: List[torch.Tensor], n_max: int = None) -> torch.Tensor:
-        """(NL+1, B, T, D) fp32.  ``n_max``: global pad-to length for data-parallel shards."""
+    def _check_inference(self, wavs):
         if torch.is_grad_enabled() and any(w.requires_grad for w in wavs):
             raise RuntimeError("s3prl_amd upstream experts are inference-only (no backward through the HIP encoder)")
-        return self._encoder_for(wavs[0].device).forward(wavs, n_max=n_max)
 
-    def forward(self, wavs: List[torch.Tensor]):
-        hs = self.encode(wavs)
+    def encode(self, wavs: List[torch.Tensor], n_max: int = None, selection: Optional[str] = None,
+               out_dtype: Optional[str] = None) -> torch.Tensor:
+        """(NS, B, T, D) on the compute GPU.  ``n_max``: global pad-to length for data-parallel shards."""
+        self._check_inference(wavs)
+        return self._encoder_for(self._compute_device(wavs)).forward(wavs, n_max=n_max, selection=selection,
+                                                                     out_dtype=out_dtype)
+
+    def encode_featurized(self, wavs: List[torch.Tensor], weights, normalize: bool = False, n_max: int = None,
+                          selection: Optional[str] = None) -> torch.Tensor:
+        """(B, T, D) fp32: the Featurizer's weighted sum computed as the encoder's epilogue (no per-layer slab)."""
+        self._check_inference(wavs)
+        return self._encoder_for(self._compute_device(wavs)).forward_featurized(wavs, weights, normalize, n_max=n_max,
+                                                                                selection=selection)
+
+    def _result(self, hs: torch.Tensor, wav_device: torch.device, full: bool = True):
+        if hs.device != wav_device:
+            hs = hs.to(wav_device)
         hidden_states = tuple(hs[l] for l in range(hs.shape[0]))
-        result = {"hidden_states": hidden_states, "last_hidden_state": hidden_states[-1]}
+        if not full:
+            return {"hidden_states": list(hidden_states)}
+        result = {"_hidden_states_info": self._states_info(len(hidden_states)), "hidden_states": hidden_states,
+                  "last_hidden_state": hidden_states[-1]}
         for i, h in enumerate(hidden_states):
             result[f"hidden_state_{i}"] = h
         return result
+
+    def forward(self, wavs: List[torch.Tensor]):
+        return self._result(self.encode(wavs), wavs[0].device)

@@ -1,18 +1,28 @@
-"""hub entries in the reference's naming (s3prl/upstream/unispeech_sat/hubconf.py:19-70); URL-named entries need the
-network, which this build never has: they accept ``ckpt=`` pointing at an already-downloaded file and otherwise raise."""
+"""hub entries in the reference's naming (s3prl/upstream/unispeech_sat/hubconf.py:19-41): ``unispeech_sat_local(ckpt, *args, **kwargs)``,
+``unispeech_sat_url(ckpt, refresh=False, ...)``.  This build has no network: URL sources raise unless they are local files."""
+
+import os
 
 from .expert import UpstreamExpert as _UpstreamExpert
 
 
-def unispeech_sat_local(ckpt: str, *args, **kwargs):
+def unispeech_sat_local(ckpt, *args, **kwargs):
+    assert os.path.isfile(ckpt), ckpt
     return _UpstreamExpert(ckpt, *args, **kwargs)
 
 
-def unispeech_sat_custom(ckpt: str, *args, **kwargs):
-    return _UpstreamExpert(ckpt, *args, **kwargs)
-
-
-def unispeech_sat(ckpt: str = None, *args, **kwargs):
-    if ckpt is None:
-        raise RuntimeError("unispeech_sat: no network in this build — pass ckpt=<checkpoint> (see unispeech_sat_local)")
+def unispeech_sat_custom(ckpt, *args, **kwargs):
     return unispeech_sat_local(ckpt, *args, **kwargs)
+
+
+def unispeech_sat_url(ckpt, refresh=False, *args, **kwargs):
+    if str(ckpt).startswith("http"):
+        raise RuntimeError(f"unispeech_sat: no network in this build, cannot fetch {ckpt} — pass a local checkpoint path")
+    return unispeech_sat_local(ckpt, *args, **kwargs)
+
+
+def unispeech_sat(refresh=False, *args, **kwargs):
+    """The reference's default entry downloads a released checkpoint; here it needs ``ckpt=`` (a local file)."""
+    if "ckpt" not in kwargs and not args:
+        raise RuntimeError("unispeech_sat: no network in this build — pass ckpt=<checkpoint> (see unispeech_sat_local)")
+    return unispeech_sat_local(*args, **kwargs)

@@ -2,10 +2,11 @@
 get_downsample_rates contract; the forward runs in libs3enc's HIP kernels).
 
 ``feature_selection`` (wav2vec2/expert.py:21,36-40,81-93): ``None`` is the hook-captured list (layer inputs + encoder
-output).  ``"fairseq_layers"`` returns every layer's OUTPUT; for post-LN models (wav2vec2-base) that is
-``hidden_states[1:]`` of the slab the library already writes.  For pre-LN models the last layer's un-normalised output,
-and for ``"fairseq_layers_before_residual"`` the pre-residual FFN outputs, are not tapped by the library — those
-selections raise instead of returning something else."""
+output, with the dict entries ``UpstreamBase.__call__`` adds).  ``"fairseq_layers"`` returns every layer's output
+(``layer_results[i][0]``: for pre-LN models the raw residual stream, including the un-normalised last layer) and
+``"fairseq_layers_before_residual"`` every layer's fc2 output before the residual (``layer_results[i][2]``); both as
+``{"hidden_states": [...]}`` only, like the reference.  The library exports those tensors directly
+(``S3ENC_SEL_LAYER_OUT`` / ``S3ENC_SEL_FFN_OUT``)."""
 
 from ..base import HipUpstreamExpert
 
@@ -17,14 +18,14 @@ class UpstreamExpert(HipUpstreamExpert):
         assert feature_selection is None or feature_selection in ["fairseq_layers", "fairseq_layers_before_residual"]
         super().__init__(ckpt, model_config, **kwargs)
         self.feature_selection = feature_selection
-        if feature_selection == "fairseq_layers_before_residual" or (
-                feature_selection == "fairseq_layers" and self.cfg.layer_norm_first):
-            raise NotImplementedError(
-                f"feature_selection={feature_selection!r} needs taps the MI355X encoder does not export "
-                f"(pre-residual FFN outputs / the un-normalised last layer of a pre-LN model)")
+
+    @property
+    def num_layers(self) -> int:
+        sel = getattr(self, "feature_selection", None)
+        return self.cfg.encoder_layers if sel else self.cfg.num_hidden_states
 
     def forward(self, wavs):
-        result = super().forward(wavs)
-        if getattr(self, "feature_selection", None) == "fairseq_layers":
-            return {"hidden_states": list(result["hidden_states"][1:])}
-        return result
+        sel = getattr(self, "feature_selection", None)
+        if sel is None:
+            return super().forward(wavs)
+        return self._result(self.encode(wavs, selection=sel), wavs[0].device, full=False)

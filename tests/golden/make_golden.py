@@ -190,7 +190,56 @@ def make_case(name: str):
     print(f"{name}: {len(hs)} x {hs[0].shape} -> {os.path.getsize(path) / 1e3:.0f} kB")
 
 
+# Featurizer / S3PRLUpstream fixtures: the reference's own ``s3prl.nn.S3PRLUpstream`` + ``s3prl.nn.Featurizer``
+# (nn/upstream.py:102-349) on a reference expert built from the seeded weights.
+# name -> (config, weight seed, wav seed, lengths, upstream normalize, featurizer normalize, layer_selections, weight seed)
+FEAT_CASES = {
+    "feat_tiny_hubert": ("tiny_hubert", 1, 41, [4000, 2345, 3111, 801], False, False, None, 5),
+    "feat_tiny_hubert_norm_sel": ("tiny_hubert", 1, 42, [3999, 2345, 3111], False, True, [0, 2, 3], 6),
+    "feat_tiny_wavlm_large_upnorm": ("tiny_wavlm_large", 8, 43, [4000, 2345, 3111], True, False, None, 7),
+    "feat_tiny_hubert_short": ("tiny_hubert", 1, 44, [640, 500], False, False, None, 8),  # < MIN_SECOND: zero-extended
+}
+
+
+def make_feat_case(name: str):
+    import torch
+
+    cfg_name, wseed, xseed, lengths, up_norm, f_norm, sel, fseed = FEAT_CASES[name]
+    cfg = named_config(cfg_name)
+    weights = synth_weights(cfg, wseed)
+    wavs = synth_wavs(lengths, xseed)
+    _import_reference()
+    from s3prl.nn.upstream import Featurizer, S3PRLUpstream
+
+    with tempfile.TemporaryDirectory() as tmp:
+        _, path = build_reference_expert(cfg, weights, tmp)
+        hub_name = {"hubert": "hubert_local", "wav2vec2": "wav2vec2_local", "wavlm": "wavlm_local"}[cfg.family]
+        up = S3PRLUpstream(hub_name, path_or_url=path, normalize=up_norm).eval()
+        feat = Featurizer(up, layer_selections=sel, normalize=f_norm).eval()
+        fw = np.random.default_rng(fseed).standard_normal(len(feat.weights)).astype(np.float32)
+        with torch.no_grad():
+            feat.weights.copy_(torch.from_numpy(fw))
+            n = max(lengths)
+            padded = torch.zeros(len(wavs), n)
+            for b, w in enumerate(wavs):
+                padded[b, : len(w)] = torch.from_numpy(w)
+            all_hs, all_lens = up(padded, torch.tensor(lengths))
+            hs, hs_len = feat(all_hs, all_lens)
+    meta = dict(config=cfg_name, weight_seed=wseed, wav_seed=xseed, lengths=lengths, upstream_normalize=up_norm,
+                featurizer_normalize=f_norm, layer_selections=sel, num_layers=len(all_hs),
+                reference="s3prl 0.4.18 @ /root/reference: s3prl.nn.S3PRLUpstream + s3prl.nn.Featurizer, torch CPU fp32")
+    arrays = {f"hs{l}": h.numpy() for l, h in enumerate(all_hs)}
+    arrays["lens"] = np.stack([x.numpy() for x in all_lens])
+    arrays["feat_weights"] = fw
+    arrays["feat"] = hs.numpy()
+    arrays["feat_len"] = hs_len.numpy()
+    arrays["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    path = os.path.join(HERE, f"{name}.npz")
+    np.savez_compressed(path, **arrays)
+    print(f"{name}: {len(all_hs)} x {tuple(all_hs[0].shape)} -> feat {tuple(hs.shape)}, {os.path.getsize(path) / 1e3:.0f} kB")
+
+
 if __name__ == "__main__":
-    names = sys.argv[1:] or list(CASES)
+    names = sys.argv[1:] or (list(CASES) + list(FEAT_CASES))
     for n in names:
-        make_case(n)
+        make_feat_case(n) if n in FEAT_CASES else make_case(n)

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     for sym in declared:
         assert hasattr(lib, sym), f"{sym} declared in s3enc.h but not exported by libs3enc.so"
     assert declared == set(_lib._PROTOS), "ctypes prototypes and header disagree"
-    assert lib.s3enc_version() == 1
+    assert lib.s3enc_version() == 2
 
 
 def test_struct_layout_matches_header(tmp_path):
@@ -42,7 +42,9 @@ def test_struct_layout_matches_header(tmp_path):
         '#include <stdio.h>\n#include <stddef.h>\n#include "s3enc.h"\n'
         'int main(void){printf("%zu %zu %zu %zu %zu\\n", sizeof(s3enc_config), sizeof(s3enc_tensor), '
         'sizeof(s3enc_profile_entry), offsetof(s3enc_config, compute_dtype), offsetof(s3enc_tensor, shape));'
-        'printf("%zu %zu\\n", sizeof(s3enc_fbank_config), offsetof(s3enc_fbank_config, cmvn_eps));return 0;}\n'
+        'printf("%zu %zu\\n", sizeof(s3enc_fbank_config), offsetof(s3enc_fbank_config, cmvn_eps));'
+        'printf("%zu %zu %zu\\n", offsetof(s3enc_config, pred_heads), sizeof(s3enc_forward_opts), '
+        'offsetof(s3enc_forward_opts, feat_w));return 0;}\n'
     )
     exe = tmp_path / "sz"
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)],
@@ -50,7 +52,8 @@ def test_struct_layout_matches_header(tmp_path):
     got = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
     assert got == [C.sizeof(_lib.S3Config), C.sizeof(_lib.S3Tensor), C.sizeof(_lib.S3ProfileEntry),
                    _lib.S3Config.compute_dtype.offset, _lib.S3Tensor.shape.offset,
-                   C.sizeof(_lib.S3FbankConfig), _lib.S3FbankConfig.cmvn_eps.offset]
+                   C.sizeof(_lib.S3FbankConfig), _lib.S3FbankConfig.cmvn_eps.offset,
+                   _lib.S3Config.pred_heads.offset, C.sizeof(_lib.S3ForwardOpts), _lib.S3ForwardOpts.feat_w.offset]
 
 
 def test_no_gpu_means_loud_failure():

@@ -1,0 +1,36 @@
+"""bench.py's launcher contract on the CPU box: `python bench.py --gpus N` with no WORLD_SIZE must start N ranks itself
+(re-exec under torch.distributed.run) and report the world size the process group really has — a run that silently
+measures one GPU under `--gpus 8` would corrupt the driver's scaling table."""
+
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra, env_extra=None):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run", "--backend", "gloo", *extra],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout  # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
+
+
+def test_gpus_n_self_launches_n_ranks():
+    line = _run(["--gpus", "2", "--batch", "3"])
+    assert line["n_gpus"] == 2 and line["exchange_ok"] and line["utterances_per_rank"] == 3 and line["scaling"] == "weak"
+
+
+def test_strong_scaling_splits_the_global_batch():
+    line = _run(["--gpus", "3", "--scaling", "strong", "--global-batch", "8"])
+    assert line["n_gpus"] == 3 and line["exchange_ok"] and line["utterances_per_rank"] == 3 and line["scaling"] == "strong"
+
+
+def test_single_rank_needs_no_launcher():
+    line = _run(["--gpus", "1"])
+    assert line["n_gpus"] == 1 and line["exchange_ok"]

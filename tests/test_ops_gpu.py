@@ -183,14 +183,14 @@ def test_layernorm(dtype, C_):
             assert O.rel_err(out16.float().cpu().numpy(), ref) < 5e-3
 
 
-def _attention_ref(qkv, valid, B, T, H, table=None, gate=None):
+def _attention_ref(qkv, valid, B, T, H, table=None, gate=None, R=None):
     D = H * 64
     q = qkv[:, :D].reshape(B, T, H, 64).transpose(0, 2, 1, 3)
     k = qkv[:, D:2 * D].reshape(B, T, H, 64).transpose(0, 2, 1, 3)
     v = qkv[:, 2 * D:].reshape(B, T, H, 64).transpose(0, 2, 1, 3)
     s = q @ k.transpose(0, 1, 3, 2)
     if table is not None:
-        idx = (np.arange(T)[None, :] - np.arange(T)[:, None]) + T - 1  # [i][j] -> (j - i) + T - 1
+        idx = np.clip(np.arange(T)[None, :] - np.arange(T)[:, None], -R, R) + R  # [i][j] -> clamp(j - i) + R
         bias = table[:, idx]  # (H,T,T)
         gt = gate if gate is not None else np.ones((B, H, T))
         s = s + gt[..., None] * bias[None]
@@ -203,8 +203,10 @@ def _attention_ref(qkv, valid, B, T, H, table=None, gate=None):
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16", "fp32x3"])
-@pytest.mark.parametrize("T,rel", [(33, False), (200, False), (149, True), (499, False)])
+@pytest.mark.parametrize("T,rel", [(33, False), (200, False), (149, 200), (499, False), (300, 40), (749, 800)])
 def test_attention(dtype, T, rel):
+    """``rel``: False, or the half-width R of the (H, 2R+1) relative-position table (R < T-1 exercises the clamp where
+    the WavLM bucket saturates, R >= T-1 the unclamped window)."""
     torch = _torch()
     from s3prl_amd import _lib
 
@@ -219,18 +221,18 @@ def test_attention(dtype, T, rel):
     valid = np.array([T, max(1, T // 3), max(1, T - 7)], dtype=np.int32)
     table = gate = None
     if rel:
-        table = rng.standard_normal((H, 2 * T - 1)).astype(np.float32)
+        table = rng.standard_normal((H, 2 * rel + 1)).astype(np.float32)
         gate = (1 + rng.random((B, H, T))).astype(np.float32)
     qr = _round(qkv, dtype).astype(np.float64)
     ref = _attention_ref(qr, valid, B, T, H, None if table is None else table.astype(np.float64),
-                         None if gate is None else gate.astype(np.float64))
+                         None if gate is None else gate.astype(np.float64), R=rel)
     dq = _dev(qkv, dtype)
     out = torch.zeros((B * T, D), device="cuda", dtype=dq.dtype)
     dvalid = torch.from_numpy(valid).cuda()
     dtable = _dev(table) if rel else None  # keep the device tensors alive across the call
     dgate = _dev(gate) if rel else None
-    rc = lib.s3enc_op_attention(_lib.DTYPES[dtype], _ptr(dq), _ptr(out), _ptr(dvalid), B, T, H, _ptr(dtable), _ptr(dgate),
-                                None)
+    rc = lib.s3enc_op_attention(_lib.DTYPES[dtype], _ptr(dq), _ptr(out), _ptr(dvalid), B, T, H, _ptr(dtable), int(rel),
+                                _ptr(dgate), None)
     _lib.check(rc, "s3enc_op_attention")
     torch.cuda.synchronize()
     got = out.float().cpu().numpy()
@@ -325,3 +327,102 @@ def test_gemm_x3_split_precision(case):
     assert err < 3e-5, f"x3 gemm {case}: rel-err {err:.3e}"
     bad = np.abs(got - ref) > 3e-4 * (1 + np.abs(ref))
     assert not bad.any(), f"{bad.sum()} elements off, first at {np.argwhere(bad)[0]}"
+
+
+# ---- conv0 + GroupNorm-from-lag-sums / LayerNorm (frontend.hip) ---------------------------------------------------------
+def _conv0_ref(wavs, n_max, normalize, w0, bias, gn, ln, stride):
+    """float64: per-utterance layer-norm -> zero pad -> Conv1d(1, C, 10, stride) -> GroupNorm(C, C) over ALL frames incl.
+    the padding | LayerNorm(C) -> GELU (wav2vec2_model.py:2879-2906)."""
+    B = len(wavs)
+    pad = np.zeros((B, n_max))
+    for b, w in enumerate(wavs):
+        w = w.astype(np.float64)
+        if normalize:
+            w = O.wav_normalize(w)
+        pad[b, :len(w)] = w
+    y = O.conv1d_channel_last(pad[:, :, None], w0.astype(np.float64)[:, None, :], None if bias is None else bias.astype(np.float64), stride)
+    if gn is not None:
+        y = O.group_norm_per_channel(y, gn[0].astype(np.float64), gn[1].astype(np.float64))
+    else:
+        y = O.layer_norm(y, ln[0].astype(np.float64), ln[1].astype(np.float64))
+    return O.gelu(y)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", ["unit", "dc_offset", "pcm_int16", "ragged_norm", "layer_norm", "layer_norm_bias"])
+def test_conv0_groupnorm_layernorm(dtype, case):
+    """conv0_kernel + gn_lag_kernel / gn_final_kernel directly: the GroupNorm statistics come from fp64 lag sums of the
+    WAVEFORM (conv0 is linear), so a large DC offset (catastrophic cancellation in a naive E[x^2]-E[x]^2) and
+    un-normalised int16-scale PCM are the cases that would break a careless implementation."""
+    torch = _torch()
+    from s3prl_amd import _lib
+
+    lib = _lib.load()
+    rng = np.random.default_rng(zlib.crc32(f"conv0/{case}".encode()))
+    C_, stride = 512, 5
+    lens = [4000, 2345, 3111] if case != "unit" else [3200, 3200]
+    wavs = [rng.standard_normal(n).astype(np.float32) for n in lens]
+    normalize = False
+    if case == "dc_offset":
+        wavs = [(1e-2 * w + 5.0).astype(np.float32) for w in wavs]
+    elif case == "pcm_int16":
+        wavs = [np.round(8000.0 * w + 300.0).clip(-32768, 32767).astype(np.float32) for w in wavs]
+    elif case == "ragged_norm":
+        wavs = [(3.0 * w - 0.7).astype(np.float32) for w in wavs]
+        normalize = True
+    w0 = (rng.standard_normal((C_, 10)) * 0.5).astype(np.float32)
+    g = (1 + 0.1 * rng.standard_normal(C_)).astype(np.float32)
+    bt = (0.05 * rng.standard_normal(C_)).astype(np.float32)
+    use_ln = case.startswith("layer_norm")
+    bias = (0.1 * rng.standard_normal(C_)).astype(np.float32) if case == "layer_norm_bias" else None
+    if use_ln:
+        normalize = True
+    n_max = max(lens)
+    L0 = (n_max - 10) // stride + 1
+    ref = _conv0_ref(wavs, n_max, normalize, w0, bias, None if use_ln else (g, bt), (g, bt) if use_ln else None, stride)
+    dw = [_dev(w) for w in wavs]
+    ptrs = (C.c_void_p * len(dw))(*[t.data_ptr() for t in dw])
+    ln_ = (C.c_int64 * len(dw))(*lens)
+    dw0, dg, db = _dev(w0), _dev(g), _dev(bt)
+    dbias = _dev(bias) if bias is not None else None
+    out = torch.zeros((len(lens), L0, C_), device="cuda", dtype={"fp32": torch.float32, "bf16": torch.bfloat16}[dtype])
+    rc = lib.s3enc_op_conv0(_lib.DTYPES[dtype], ptrs, ln_, len(lens), 0, int(normalize), _ptr(dw0), _ptr(dbias),
+                            None if use_ln else _ptr(dg), None if use_ln else _ptr(db), _ptr(dg) if use_ln else None,
+                            _ptr(db) if use_ln else None, C_, stride, _ptr(out), None)
+    _lib.check(rc, "s3enc_op_conv0")
+    torch.cuda.synchronize()
+    got = out.float().cpu().numpy()
+    assert np.isfinite(got).all()
+    err = O.rel_err(got, ref)
+    # fp32: conv + norm in fp32 with fp64 statistics; bf16: only the output is rounded (2^-9 relative per element)
+    tol = {"fp32": 2e-5, "bf16": 4e-3}[dtype]
+    assert err < tol, f"conv0 {case}/{dtype}: rel-err {err:.3e}"
+    if not use_ln:  # the padded tail is part of the GroupNorm statistics AND is produced (frames of zeros -> gelu(beta'))
+        b_short = int(np.argmin(lens))
+        tail = got[b_short, (lens[b_short] // stride) + 2:]
+        assert O.rel_err(tail, ref[b_short, (lens[b_short] // stride) + 2:]) < tol * 5 + 1e-6
+
+
+def test_wavlm_gate_kernel():
+    """wavlm_gate_kernel against the float64 formula of wavlm/modules.py:535-549:
+    gate = a * (b * grep_a - 1) + 2 with a, b = sigmoid(sum over 4 of grep_linear(x_head))."""
+    torch = _torch()
+    from s3prl_amd import _lib
+
+    lib = _lib.load()
+    rng = np.random.default_rng(77)
+    for (B, T, H) in [(2, 37, 12), (3, 200, 16), (1, 5, 2)]:
+        x = rng.standard_normal((B, T, H * 64)).astype(np.float32) * 1.5
+        gw = (rng.standard_normal((8, 64)) * 0.2).astype(np.float32)
+        gb = (rng.standard_normal(8) * 0.3).astype(np.float32)
+        ga = (1 + 0.3 * rng.standard_normal(H)).astype(np.float32)
+        xh = x.astype(np.float64).reshape(B, T, H, 64).transpose(0, 2, 1, 3)
+        gl = (xh @ gw.astype(np.float64).T + gb).reshape(B, H, T, 2, 4).sum(-1)
+        sg = 1.0 / (1.0 + np.exp(-gl))
+        ref = sg[..., 0] * (sg[..., 1] * ga.astype(np.float64)[None, :, None] - 1.0) + 2.0  # (B, H, T)
+        dx, dgw, dgb, dga = _dev(x), _dev(gw), _dev(gb), _dev(ga)
+        out = torch.zeros((B, H, T), device="cuda")
+        _lib.check(lib.s3enc_op_wavlm_gate(_ptr(dx), _ptr(dgw), _ptr(dgb), _ptr(dga), B, T, H, _ptr(out), None), "s3enc_op_wavlm_gate")
+        torch.cuda.synchronize()
+        err = O.rel_err(out.cpu().numpy(), ref)
+        assert err < 5e-6, f"wavlm gate {B}x{T}x{H}: rel-err {err:.3e}"
