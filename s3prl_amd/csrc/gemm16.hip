@@ -340,6 +340,7 @@ hipError_t launch_gemm16_big(int dtype, const GemmParams& p, hipStream_t stream)
         const long t192 = ((p.M + 191) / 192) * ((p.N + 255) / 256) * p.batches;
         if (mode == 4 && t192 <= 256 && t192 >= 224) mode = 6;
     }
+    if (mode >= 7) return launch_gemm16_phased(dtype, mode, p, stream);  // gemm16p.hip
     return dtype == BF16 ? big_mode<bf16_tag>(mode, p, stream) : big_mode<f16_tag>(mode, p, stream);
 }
 

@@ -46,6 +46,11 @@ void pack_x3(const float* w, long N, long K, std::vector<uint16_t>& out);  // ho
 extern int g_gemm16_big;
 bool gemm16_big_eligible(int dtype, const GemmParams& p);
 hipError_t launch_gemm16_big(int dtype, const GemmParams& p, hipStream_t stream);
+// gemm16p.hip: phase-pipelined 256x256 tile (staggered wave rows, region-granular LDS-DMA ring, counted vmcnt)
+extern int g_gemm16_probe;
+extern int g_gemm_x3_mode;  // 0: gemm_x3.hip (two-stage lockstep), 1: the phased schedule of gemm16p.hip
+hipError_t launch_gemm_x3_phased(const GemmParams& p, hipStream_t stream);
+hipError_t launch_gemm16_phased(int dtype, int mode, const GemmParams& p, hipStream_t stream);
 hipError_t launch_gemm(int dtype, const GemmParams& p, hipStream_t stream);
 
 // ---- frontend.hip ---------------------------------------------------------------------------------------

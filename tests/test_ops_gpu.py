@@ -59,11 +59,11 @@ def test_gemm_variants(dtype, case, variant):
         _lib.check(lib.s3enc_set_tuning(b"gemm_variant", 3))
 
 
-@pytest.mark.parametrize("mode", [1, 2, 4, 5, 6, 0])
+@pytest.mark.parametrize("mode", [1, 2, 4, 5, 6, 7, 8, 9, 0])
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("case", ["big_plain", "big_conv", "big_epilogue", "big_edge"])
 def test_gemm16_big_tiles(dtype, case, mode):
-    """The large-tile LDS-DMA kernel of the 16-bit modes (gemm16.hip): 256x256 (mode 1) and 128x256 (mode 2) tiles on
+    """The large-tile LDS-DMA kernels of the 16-bit modes (gemm16.hip; mode 7 = the phase-pipelined gemm16p.hip): 256x256 (mode 1) and 128x256 (mode 2) tiles on
     shapes that span several tiles with ragged M / N edges, overlapping conv rows, batches and the full epilogue;
     mode 0 runs the same shapes through the 128x128 kernel."""
     from s3prl_amd import _lib
@@ -274,8 +274,9 @@ def test_posconv(dtype, shape):
     assert err < TOL[dtype], f"posconv {dtype}/{shape}: rel-err {err:.3e}"
 
 
+@pytest.mark.parametrize("schedule", [0, 1])
 @pytest.mark.parametrize("case", ["big_plain", "big_conv", "big_epilogue", "x3_long"])
-def test_gemm_x3_split_precision(case):
+def test_gemm_x3_split_precision(case, schedule):
     """gemm_x3.hip: fp32 operands, every product rebuilt from three bf16 MFMAs (hi*hi + lo*hi + hi*lo).  Against the
     float64 product of the UNROUNDED fp32 operands the error must sit at the 1e-5 level (vs 3e-3 for plain bf16 and
     1e-6 for the exact kernel), on multi-tile shapes with ragged edges, overlapping conv rows and the full epilogue."""
@@ -283,6 +284,7 @@ def test_gemm_x3_split_precision(case):
     from s3prl_amd import _lib
 
     lib = _lib.load()
+    _lib.check(lib.s3enc_set_tuning(b"gemm_x3_mode", schedule))  # 0: gemm_x3.hip, 1: the phased schedule (gemm16p.hip)
     rng = np.random.default_rng(zlib.crc32(f"x3/{case}".encode()))
     act, use_res, use_lim = 0, False, False
     Cc, Lin = 128, 1101
@@ -320,6 +322,7 @@ def test_gemm_x3_split_precision(case):
     out = torch.full((batches, M, N), float("nan"), device="cuda")
     rc = lib.s3enc_op_gemm(3, _ptr(dA), lda, a_bs, _ptr(dW), _ptr(dbias), M, N, K, batches, act,
                            _ptr(dres) if use_res else None, _ptr(dlim) if use_lim else None, _ptr(out), None, N, M * N, None)
+    _lib.check(lib.s3enc_set_tuning(b"gemm_x3_mode", 0))
     _lib.check(rc, "s3enc_op_gemm x3")
     got = out.cpu().numpy()
     assert np.isfinite(got).all()
@@ -396,6 +399,11 @@ def test_conv0_groupnorm_layernorm(dtype, case):
     err = O.rel_err(got, ref)
     # fp32: conv + norm in fp32 with fp64 statistics; bf16: only the output is rounded (2^-9 relative per element)
     tol = {"fp32": 2e-5, "bf16": 4e-3}[dtype]
+    if case == "dc_offset":
+        # signal std 0.015 on a conv output of magnitude ~8: the fp32 conv products round at 8 * 2^-24 BEFORE the mean is
+        # removed (the reference's fp32 conv1d has the same rounding), i.e. ~3e-5 of the centred signal; what this case
+        # guards against is the statistics losing digits (E[y^2] - E[y]^2 in fp32 would be off by > 1e-1 here)
+        tol = max(tol, 2e-4)
     assert err < tol, f"conv0 {case}/{dtype}: rel-err {err:.3e}"
     if not use_ln:  # the padded tail is part of the GroupNorm statistics AND is produced (frames of zeros -> gelu(beta'))
         b_short = int(np.argmin(lens))

@@ -28,11 +28,15 @@ SHAPES = {  # name: (batches, M, N, K, lda, a_bs_rows)
 }
 
 def run(dtype, variants=None, rounds=5, shapes=None, reps=10):
-    big = dtype != "fp32"
+    x3 = dtype == "fp32x3"  # variants: gemm_x3_mode 0 / 1
+    big = dtype not in ("fp32", "fp32x3")
+    if x3 and variants is None:
+        variants = (0, 1)
     if variants is None:
         # 16-bit modes: the large-tile kernel's configurations (gemm16_big; 0 = the 128x128 kernel); fp32: staging variants
-        variants = (0, 1, 4, 5, 6) if big else (1, 3, 0, 2)
-    td = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[dtype]
+        variants = (0, 1, 4, 5, 6, 7) if big else (1, 3, 0, 2)
+    td = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16, "fp32x3": torch.float32}[dtype]
+    _lib.check(lib.s3enc_set_tuning(b"x3_pack_cache", 1 if x3 else 0))
     print(f"== {dtype}")
     for name, (nb, M, N, K, lda, rows) in SHAPES.items():
         if shapes and name not in shapes:
@@ -48,26 +52,32 @@ def run(dtype, variants=None, rounds=5, shapes=None, reps=10):
         resid = name.split("_")[-1] in ("proj", "out", "fc2") or name.endswith("fc2")
         act = 0 if (resid or "qkv" in name) else 1
         res32 = torch.randn(nb * M * N, device="cuda") if resid else None
-        out32 = torch.empty(nb * M * N, device="cuda") if (dtype == "fp32" or resid) else None
-        out16 = torch.empty(nb * M * N, device="cuda", dtype=td) if (dtype != "fp32" and not resid) else None
+        out32 = torch.empty(nb * M * N, device="cuda") if (not big or resid) else None
+        out16 = torch.empty(nb * M * N, device="cuda", dtype=td) if (big and not resid) else None
         p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
         res = {v: [] for v in variants}
         ref = None
         for r in range(rounds + 1):
             for v in variants:
-                _lib.check(lib.s3enc_set_tuning(b"gemm16_big" if big else b"gemm_variant", v))
+                if x3:
+                    _lib.check(lib.s3enc_set_tuning(b"gemm_x3_mode", v))
+                elif big:  # v >= 100: timing probe (v - 100) of the phase-pipelined kernel (mode 7); results are garbage
+                    _lib.check(lib.s3enc_set_tuning(b"gemm16_big", 7 if v >= 100 else v))
+                    _lib.check(lib.s3enc_set_tuning(b"gemm16_probe", v - 100 if v >= 100 else 0))
+                else:
+                    _lib.check(lib.s3enc_set_tuning(b"gemm_variant", v))
                 torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(reps):  # back-to-back launches: one launch alone is dominated by clock ramp / launch gaps
-                    _lib.check(lib.s3enc_op_gemm(_lib.DTYPES[dtype], p(A), lda, a_bs, p(W), p(bias), M, N, K, nb, act, p(res32),
+                    _lib.check(lib.s3enc_op_gemm(3 if x3 else _lib.DTYPES[dtype], p(A), lda, a_bs, p(W), p(bias), M, N, K, nb, act, p(res32),
                                                  None, p(out32), p(out16), N, M * N, None))
                 e1.record(); torch.cuda.synchronize()
                 if r: res[v].append(e0.elapsed_time(e1) / reps)
                 o = (out32 if out32 is not None else out16).float()
                 chk = float(o[:: 9973].double().sum())
-                if ref is None: ref = chk
-                assert not CHECK or abs(chk - ref) <= 1e-3 * abs(ref) + 1e-3, (name, v, chk, ref)
+                if ref is None and v < 100: ref = chk
+                assert not CHECK or v >= 100 or abs(chk - ref) <= 1e-3 * abs(ref) + 1e-3, (name, v, chk, ref)
         fl = 2.0 * nb * M * N * K
         print(f"  {name:9s}", "  ".join(f"v{v}: {min(t):7.3f} ms {fl / min(t) / 1e9:7.1f} TF" for v, t in res.items()))
 

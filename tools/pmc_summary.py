@@ -35,6 +35,10 @@ for key, c in agg.items():
         d["lds_conflict"] = v.get("SQ_LDS_BANK_CONFLICT", 0) / v["SQ_LDS_IDX_ACTIVE"]
     if v.get("SQ_BUSY_CU_CYCLES") and "SQ_VALU_MFMA_BUSY_CYCLES" in v:
         d["mfma_busy"] = v["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * v["SQ_BUSY_CU_CYCLES"])
+    if v.get("GRBM_GUI_ACTIVE") and us == us and us > 0:
+        d["gui_cyc_per_ns"] = v["GRBM_GUI_ACTIVE"] / (us * 1e3)  # effective clock in GHz (x number of counted instances)
+    if v.get("SQ_INSTS_VALU") and v.get("SQ_WAVE_CYCLES"):
+        d["valu_per_kcyc"] = 1e3 * v["SQ_INSTS_VALU"] / v["SQ_WAVE_CYCLES"]
     if "TCC_HIT_sum" in v:
         d["l2_hit"] = v["TCC_HIT_sum"] / max(1.0, v["TCC_HIT_sum"] + v.get("TCC_MISS_sum", 0))
     if "FETCH_SIZE" in v:
@@ -43,7 +47,7 @@ for key, c in agg.items():
         d["write_MB"] = v["WRITE_SIZE"] / 1024.0
     rows.append((us * n if us == us else 0, key, n, us, d, v))
 rows.sort(key=lambda r: -r[0])
-cols = ["mfma_busy", "wait_any", "wait_inst", "wait_inst_lds", "active", "lds_conflict", "l2_hit", "fetch_MB", "write_MB"]
+cols = ["mfma_busy", "wait_any", "wait_inst", "wait_inst_lds", "active", "lds_conflict", "gui_cyc_per_ns", "l2_hit", "fetch_MB", "write_MB"]
 print("| kernel | grid | calls/pass | avg us (profiled) | " + " | ".join(cols) + " |")
 print("|---|---:|---:|---:|" + "---:|" * len(cols))
 for _, (name, grid), n, us, d, v in rows[:40]:
