@@ -90,9 +90,43 @@ __device__ __forceinline__ float gelu_fast(float x) {
     return 0.5f * x * (1.0f + erf);
 }
 
+// The same erf-GELU on a PAIR of values with packed fp32 VALU (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32: one issue slot
+// for two lanes' worth of work; the two transcendentals and the sign transfer stay per element): ~11 issue slots per
+// element instead of 19.  For epilogues and elementwise kernels only — beside MFMAs packed fp32 is an anti-lever
+// (MI355X_MICROARCH.md, per-instruction constants).  Bit-identical to gelu_fast per element (same operations, same order).
+__device__ __forceinline__ f32x2 gelu_fast2(f32x2 x) {
+    const f32x2 ax = {__builtin_fabsf(x.x), __builtin_fabsf(x.y)};
+    const f32x2 z = ax * 0.70710678118654752440f;
+    const f32x2 d = __builtin_elementwise_fma(z, (f32x2){0.3275911f, 0.3275911f}, (f32x2){1.0f, 1.0f});
+    const f32x2 t = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+    f32x2 poly = __builtin_elementwise_fma(t, (f32x2){1.061405429f, 1.061405429f}, (f32x2){-1.453152027f, -1.453152027f});
+    poly = __builtin_elementwise_fma(poly, t, (f32x2){1.421413741f, 1.421413741f});
+    poly = __builtin_elementwise_fma(poly, t, (f32x2){-0.284496736f, -0.284496736f});
+    poly = __builtin_elementwise_fma(poly, t, (f32x2){0.254829592f, 0.254829592f});
+    poly = poly * t;
+    const f32x2 zz = (z * -1.44269504088896340736f) * z;
+    const f32x2 e = {__builtin_amdgcn_exp2f(zz.x), __builtin_amdgcn_exp2f(zz.y)};
+    const f32x2 erf_abs = __builtin_elementwise_fma(-poly, e, (f32x2){1.0f, 1.0f});
+    const f32x2 erf = {__builtin_copysignf(erf_abs.x, x.x), __builtin_copysignf(erf_abs.y, x.y)};
+    return (x * 0.5f) * (erf + 1.0f);
+}
+__device__ __forceinline__ void gelu_fast4(float4& v) {
+    const f32x2 a = gelu_fast2((f32x2){v.x, v.y}), b = gelu_fast2((f32x2){v.z, v.w});
+    v = make_float4(a.x, a.y, b.x, b.y);
+}
+
 // GELU of the compute mode: libm-exact erf for the fp32 path, the fast erf for the 16-bit operand modes
 template <typename T> __device__ __forceinline__ float gelu_mode(float x) { return gelu_fast(x); }
 template <> __device__ __forceinline__ float gelu_mode<float>(float x) { return gelu_erf(x); }
+// four values at once: FAST = the packed 1.5e-7 erf (16-bit operand modes and the split-precision mode), else libm erff
+template <bool FAST> __device__ __forceinline__ void gelu4(float& a, float& b, float& c, float& d) {
+    if constexpr (FAST) {
+        const f32x2 p = gelu_fast2((f32x2){a, b}), q = gelu_fast2((f32x2){c, d});
+        a = p.x; b = p.y; c = q.x; d = q.y;
+    } else {
+        a = gelu_erf(a); b = gelu_erf(b); c = gelu_erf(c); d = gelu_erf(d);
+    }
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -866,6 +866,7 @@ int forward_impl(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
         p.s0 = c.conv_stride[0];
         p.L0 = L[0];
         p.out = actA;
+        p.fast = e->x3;
         Prof pr(e, st, "conv0", 2.0 * B * L[0] * C * p.k0, 4.0 * B * n_max + (double)B * L[0] * C * es);
         HIP_TRY(launch_conv0(dt, p, st));
     }
@@ -907,7 +908,7 @@ int forward_impl(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
             }
             Prof pr(e, st, "layernorm:conv", 0, (double)B * L[i] * C * (4 + (f32out ? 4 : es)));
             HIP_TRY(launch_layernorm(dt, (const float*)tmp32, (const float*)e->conv[i].lng.p, (const float*)e->conv[i].lnb.p,
-                                     (long)B * L[i], C, 1, f32out ? (float*)dst : nullptr, f32out ? nullptr : dst, st));
+                                     (long)B * L[i], C, e->x3 ? 2 : 1, f32out ? (float*)dst : nullptr, f32out ? nullptr : dst, st));
         }
         char tn[16];
         snprintf(tn, sizeof(tn), "conv%d", i);

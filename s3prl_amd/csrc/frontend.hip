@@ -142,9 +142,17 @@ constexpr int C0_FT = 64;  // frames per block
 // CS = waves that share one frame, each owning a contiguous C / CS slice of the channels (GroupNorm mode only: no
 // reduction across channels).  CS = 2 for C = 512 halves the per-lane weight registers (149 -> 81 VGPRs, 3 -> 5-6 waves
 // per SIMD), which is what lets the GELU arithmetic of one wave overlap the 1 KiB row stores of another.
-template <typename T, int NG, int K0, int CS = 1>
+// FAST: packed fp32 arithmetic for the taps (v_pk_fma_f32 on channel pairs) and the packed 1.5e-7 erf-GELU — the 16-bit
+// operand modes and the split-precision mode (this kernel is VALU-bound there: 40 FMAs + ~80 GELU slots per 4 outputs);
+// the exact fp32 mode keeps scalar FMAs in tap order and libm erff.
+template <typename T, int NG, int K0, int CS = 1, bool FAST = false>
 __global__ __launch_bounds__(256) void conv0_kernel(Conv0Params p) {
     typedef typename Cvt<T>::store_t store_t;
+    // 16-bit output with two channel groups per lane: the lane owns 8 CONSECUTIVE channels (groups g = 0, 1 are channels
+    // 8*lane + 4*g ..) so that a row is written with one 16-byte store per lane — 8-byte stores are issue-bound at
+    // ~2.4 TB/s here, 16-byte ones reach the fp32 variant's 3.6+ TB/s
+    constexpr bool WIDE = sizeof(store_t) == 2 && NG == 2 && CS == 1;
+    auto chan0 = [&](int lane_, int g, int coff_) { return WIDE ? coff_ + 8 * lane_ + 4 * g : coff_ + 4 * (lane_ + 64 * g); };
     __shared__ float xs[(C0_FT - 1) * 8 + STAT_K0_MAX];  // stride <= 8 supported
     const int b = blockIdx.y;
     const long t0 = (long)blockIdx.x * C0_FT;
@@ -163,7 +171,7 @@ __global__ __launch_bounds__(256) void conv0_kernel(Conv0Params p) {
     bool act[NG];
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-        const int c0 = coff + 4 * (lane + 64 * g);
+        const int c0 = chan0(lane, g, coff);
         act[g] = c0 < p.C;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -192,19 +200,33 @@ __global__ __launch_bounds__(256) void conv0_kernel(Conv0Params p) {
         for (int j = 0; j < K0; ++j) xv[j] = xs[f * p.s0 + j];
         float v[NG][4];
 #pragma unroll
-        for (int g = 0; g < NG; ++g)
+        for (int g = 0; g < NG; ++g) {
+            if constexpr (FAST) {  // same per-channel tap order, two channels per instruction
+                f32x2 s01 = {0.f, 0.f}, s23 = {0.f, 0.f};
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                float s = 0.f;
+                for (int j = 0; j < K0; ++j) {
+                    const f32x2 xx = {xv[j], xv[j]};
+                    s01 = __builtin_elementwise_fma((f32x2){w[g][0][j], w[g][1][j]}, xx, s01);
+                    s23 = __builtin_elementwise_fma((f32x2){w[g][2][j], w[g][3][j]}, xx, s23);
+                }
+                v[g][0] = s01.x; v[g][1] = s01.y; v[g][2] = s23.x; v[g][3] = s23.y;
+            } else {
 #pragma unroll
-                for (int j = 0; j < K0; ++j) s = fmaf(w[g][u][j], xv[j], s);
-                v[g][u] = s;
+                for (int u = 0; u < 4; ++u) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int j = 0; j < K0; ++j) s = fmaf(w[g][u][j], xv[j], s);
+                    v[g][u] = s;
+                }
             }
+        }
         if (p.gn) {
 #pragma unroll
-            for (int g = 0; g < NG; ++g)
+            for (int g = 0; g < NG; ++g) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) v[g][u] = gelu_mode<T>(fmaf(v[g][u], a0[g][u], a1[g][u]));
+                for (int u = 0; u < 4; ++u) v[g][u] = fmaf(v[g][u], a0[g][u], a1[g][u]);
+                gelu4<FAST>(v[g][0], v[g][1], v[g][2], v[g][3]);
+            }
         } else {
             // Fp32LayerNorm over the C channels of this frame (wav2vec2_model.py:2887-2897), two-pass
             float s = 0.f;
@@ -226,15 +248,24 @@ __global__ __launch_bounds__(256) void conv0_kernel(Conv0Params p) {
                 }
             const float rs = rsqrtf(wave_sum(q) * invC + LN_EPS);
 #pragma unroll
-            for (int g = 0; g < NG; ++g)
+            for (int g = 0; g < NG; ++g) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) v[g][u] = gelu_mode<T>((v[g][u] - mu) * rs * a0[g][u] + a1[g][u]);
+                for (int u = 0; u < 4; ++u) v[g][u] = (v[g][u] - mu) * rs * a0[g][u] + a1[g][u];
+                gelu4<FAST>(v[g][0], v[g][1], v[g][2], v[g][3]);
+            }
         }
         store_t* o = (store_t*)p.out + ((long)b * p.L0 + t) * p.C;
+        if constexpr (WIDE) {
+            if (act[0])  // C % 8 == 0 on this path (launcher): both groups are in or out together
+                *(uint4*)(o + chan0(lane, 0, coff)) =
+                    make_uint4(Cvt<T>::pack2(v[0][0], v[0][1]), Cvt<T>::pack2(v[0][2], v[0][3]),
+                               Cvt<T>::pack2(v[1][0], v[1][1]), Cvt<T>::pack2(v[1][2], v[1][3]));
+            continue;
+        }
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             if (!act[g]) continue;
-            const int c0 = coff + 4 * (lane + 64 * g);
+            const int c0 = chan0(lane, g, coff);
             if constexpr (sizeof(store_t) == 4) {
                 *(float4*)(o + c0) = make_float4(v[g][0], v[g][1], v[g][2], v[g][3]);
             } else {
@@ -249,18 +280,20 @@ __global__ __launch_bounds__(256) void conv0_kernel(Conv0Params p) {
     }
 }
 
-template <typename T>
+template <typename T, bool FAST>
 hipError_t conv0_dispatch(const Conv0Params& p, hipStream_t s) {
     dim3 grid((unsigned)((p.L0 + C0_FT - 1) / C0_FT), p.wav.B);
     const int ng = (p.C + 255) / 256;
     if (ng <= 1)
-        hipLaunchKernelGGL((conv0_kernel<T, 1, 10>), grid, dim3(256), 0, s, p);
+        hipLaunchKernelGGL((conv0_kernel<T, 1, 10, 1, FAST>), grid, dim3(256), 0, s, p);
+    // (16-bit GroupNorm extractors also go through the two-waves-per-frame variant with 8-byte stores: the one-wave,
+    //  8-channels-per-lane variant with 16-byte row stores needs 134 VGPRs and measured 0.71 ms against 0.42 ms)
     else if (ng == 2 && p.gn)  // GroupNorm extractor (base models): two waves per frame, 256 channels each
-        hipLaunchKernelGGL((conv0_kernel<T, 1, 10, 2>), grid, dim3(256), 0, s, p);
+        hipLaunchKernelGGL((conv0_kernel<T, 1, 10, 2, FAST>), grid, dim3(256), 0, s, p);
     else if (ng == 2)
-        hipLaunchKernelGGL((conv0_kernel<T, 2, 10>), grid, dim3(256), 0, s, p);
+        hipLaunchKernelGGL((conv0_kernel<T, 2, 10, 1, FAST>), grid, dim3(256), 0, s, p);
     else
-        hipLaunchKernelGGL((conv0_kernel<T, 4, 10>), grid, dim3(256), 0, s, p);
+        hipLaunchKernelGGL((conv0_kernel<T, 4, 10, 1, FAST>), grid, dim3(256), 0, s, p);
     return hipGetLastError();
 }
 
@@ -292,9 +325,9 @@ hipError_t launch_conv0(int dtype, const Conv0Params& p, hipStream_t s) {
     // the kernel is specialised for the first layer every released checkpoint has: k = 10, stride <= 8, C <= 1024
     if (p.k0 != 10 || p.s0 > 8 || p.s0 < 1 || p.C > 1024 || (p.C & 3)) return hipErrorInvalidValue;
     switch (dtype) {
-        case F32: return conv0_dispatch<float>(p, s);
-        case BF16: return conv0_dispatch<bf16_tag>(p, s);
-        case F16: return conv0_dispatch<f16_tag>(p, s);
+        case F32: return p.fast ? conv0_dispatch<float, true>(p, s) : conv0_dispatch<float, false>(p, s);
+        case BF16: return conv0_dispatch<bf16_tag, true>(p, s);
+        case F16: return conv0_dispatch<f16_tag, true>(p, s);
     }
     return hipErrorInvalidValue;
 }

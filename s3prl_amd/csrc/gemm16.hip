@@ -234,6 +234,49 @@ __global__ __launch_bounds__(128 * WN, WPE) void gemm16_big_kernel(GemmParams p)
         const bool res = SPEC ? decltype(res_c)::value : (p.residual != nullptr);
         const bool o32 = SPEC ? decltype(o32_c)::value : (p.out32 != nullptr);
         const bool o16 = SPEC ? decltype(o16_c)::value : (p.out16 != nullptr);
+        if constexpr (SPEC && decltype(o16_c)::value && !decltype(o32_c)::value && !decltype(res_c)::value) {
+            // 16-bit output only (conv1-5, q|k|v, fc1): 8 lanes x 8 columns per row, ONE 16-byte store per lane and pass
+            // (8-byte stores are issue-bound at 2.1-2.8 TB/s on this chip, 16-byte ones reach 5 TB/s: profiles/r02_gemm16_variants.md)
+            if (!(p.N & 7)) {
+                const int c8 = (lane & 7) * 8;
+                const int n8 = n0 + wc * 64 + c8;
+                const bool n8_ok = n8 < p.N;
+                float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+                if (p.bias && n8_ok) {
+                    b0 = *(const float4*)(p.bias + n8);
+                    b1 = *(const float4*)(p.bias + n8 + 4);
+                }
+                #pragma unroll
+                for (int i = 0; i < MI; ++i) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            stg[((r & 3) + 8 * (r >> 2) + 4 * half) * 64 + j * 32 + l31] = acc[i][j][r];
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) {
+                        const int row = tt * 8 + (lane >> 3);
+                        float4 v = *(const float4*)(stg + row * 64 + c8);
+                        float4 w = *(const float4*)(stg + row * 64 + c8 + 4);
+                        const int m = m0 + wr * WTM + i * 32 + row;
+                        if (m < p.M && n8_ok) {
+                            v.x += b0.x; v.y += b0.y; v.z += b0.z; v.w += b0.w;
+                            w.x += b1.x; w.y += b1.y; w.z += b1.z; w.w += b1.w;
+                            if (act) {
+                                gelu_fast4(v);
+                                gelu_fast4(w);
+                            }
+                            const long o = ob + (long)m * p.ldo + n8;
+                            *(uint4*)((store_t*)p.out16 + o) = make_uint4(Cvt<T>::pack2(v.x, v.y), Cvt<T>::pack2(v.z, v.w),
+                                                                          Cvt<T>::pack2(w.x, w.y), Cvt<T>::pack2(w.z, w.w));
+                        }
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+                return;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
 #pragma unroll
@@ -250,7 +293,7 @@ __global__ __launch_bounds__(128 * WN, WPE) void gemm16_big_kernel(GemmParams p)
                 if (m < p.M && n_ok) {
                     v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
                     if (act) {
-                        v.x = gelu_fast(v.x); v.y = gelu_fast(v.y); v.z = gelu_fast(v.z); v.w = gelu_fast(v.w);
+                        gelu_fast4(v);
                     }
                     const long o = ob + (long)m * p.ldo + n;
                     if (res) {
@@ -329,16 +372,12 @@ bool gemm16_big_eligible(int dtype, const GemmParams& p) {
 hipError_t launch_gemm16_big(int dtype, const GemmParams& p, hipStream_t stream) {
     int mode = g_gemm16_big;
     if (mode == 3) {
-        // measured on MI355X (tools/gemm_bench.py, profiles/r01_gemm16_variants.md, and in the full forward with
-        // `bench.py --tune gemm16_big=1|4`): long K loops amortise the serial prologue/epilogue of a
-        // one-workgroup-per-CU 256x256 tile and gain from its 128 FLOP per staged byte; short ones (K = 768) are
-        // as fast or faster with two 128x256 workgroups per CU hiding each other's barriers and
-        // epilogues
-        mode = p.K >= 1024 ? 1 : 4;
-        // a short-K GEMM that is exactly one round of 192-row tiles (out_proj at M = 15968, N = 768: 252 tiles on 256
-        // CUs) is faster there than as 375 128-row tiles on 512 slots: 31 vs 36 us
-        const long t192 = ((p.M + 191) / 192) * ((p.N + 255) / 256) * p.batches;
-        if (mode == 4 && t192 <= 256 && t192 >= 224) mode = 6;
+        // measured on MI355X (tools/gemm_bench.py, profiles/r02_gemm16_variants.md, and in the full forward with
+        // `bench.py --tune gemm16_big=1|4`): with 16-byte stores in the 16-bit epilogues the one-workgroup-per-CU 256x256 /
+        // 192x256 tile (mode 1 picks the one that leaves fewer idle CU-rounds) wins on every shape of the path —
+        // q|k|v 64 vs 72 us, fc1 99 vs 104, out_proj 33 vs 37 against two 128x256 workgroups per CU (mode 4), which
+        // round 1 preferred for K = 768 when the epilogue's 8-byte stores were the longer part of a tile
+        mode = 1;
     }
     if (mode >= 7) return launch_gemm16_phased(dtype, mode, p, stream);  // gemm16p.hip
     return dtype == BF16 ? big_mode<bf16_tag>(mode, p, stream) : big_mode<f16_tag>(mode, p, stream);

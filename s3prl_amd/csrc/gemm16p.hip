@@ -314,6 +314,51 @@ __global__ __launch_bounds__(512, 2) void gemm16_ph_kernel(GemmParams p) {
         const bool res = SPEC ? decltype(res_c)::value : (p.residual != nullptr);
         const bool o32 = SPEC ? decltype(o32_c)::value : (p.out32 != nullptr);
         const bool o16 = SPEC ? decltype(o16_c)::value : (p.out16 != nullptr);
+        if constexpr (!X3 && SPEC && decltype(o16_c)::value && !decltype(o32_c)::value && !decltype(res_c)::value) {
+            // 16-bit output only (conv1-5, q|k|v, fc1): 8 lanes x 8 columns per row, ONE 16-byte store per lane and pass
+            // (8-byte stores are issue-bound at 2.1-2.8 TB/s on this chip, 16-byte ones reach 5 TB/s: profiles/r02_gemm16_variants.md)
+            if (!(p.N & 7)) {
+                const int c8 = (lane & 7) * 8;
+                const int n8 = n0 + wc * 64 + c8;
+                const bool n8_ok = n8 < p.N;
+                float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+                if (p.bias && n8_ok) {
+                    b0 = *(const float4*)(p.bias + n8);
+                    b1 = *(const float4*)(p.bias + n8 + 4);
+                }
+                #pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            stg[((r & 3) + 8 * (r >> 2) + 4 * half) * 64 + j * 32 + l31] = acc[i][j][u][r];
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) {
+                        const int row = tt * 8 + (lane >> 3);
+                        float4 v = *(const float4*)(stg + row * 64 + c8);
+                        float4 w = *(const float4*)(stg + row * 64 + c8 + 4);
+                        const int m = m0 + i * 128 + wr * 64 + u * 32 + row;
+                        if (m < p.M && n8_ok) {
+                            v.x += b0.x; v.y += b0.y; v.z += b0.z; v.w += b0.w;
+                            w.x += b1.x; w.y += b1.y; w.z += b1.z; w.w += b1.w;
+                            if (act) {
+                                gelu_fast4(v);
+                                gelu_fast4(w);
+                            }
+                            const long o = ob + (long)m * p.ldo + n8;
+                            *(uint4*)((store_t*)p.out16 + o) = make_uint4(Cvt<T>::pack2(v.x, v.y), Cvt<T>::pack2(v.z, v.w),
+                                                                          Cvt<T>::pack2(w.x, w.y), Cvt<T>::pack2(w.z, w.w));
+                        }
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+                return;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -332,7 +377,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_ph_kernel(GemmParams p) {
                     if (m < p.M && n_ok) {
                         v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
                         if (act) {
-                            v.x = gelu_fast(v.x); v.y = gelu_fast(v.y); v.z = gelu_fast(v.z); v.w = gelu_fast(v.w);
+                            gelu_fast4(v);
                         }
                         const long o = ob + (long)m * p.ldo + n;
                         if (res) {

@@ -183,7 +183,7 @@ __global__ __launch_bounds__(512, 2) void gemm_x3_kernel(GemmParams p) {
                 if (m < p.M && n_ok) {
                     v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
                     if (ACT) {
-                        v.x = gelu_fast(v.x); v.y = gelu_fast(v.y); v.z = gelu_fast(v.z); v.w = gelu_fast(v.w);
+                        gelu_fast4(v);
                     }
                     const long o = ob + (long)m * p.ldo + n;
                     if (RES) {

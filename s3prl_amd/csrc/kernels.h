@@ -81,6 +81,7 @@ struct Conv0Params {
     int C, k0, s0;
     long L0;
     void* out;            // (B, L0, C) compute dtype
+    int fast = 0;         // fp32 output with the packed 1.5e-7 erf-GELU (the split-precision mode S3ENC_F32X3)
 };
 hipError_t launch_conv0(int dtype, const Conv0Params& p, hipStream_t s);
 
@@ -93,6 +94,7 @@ struct LnAcc {
     int norm = 0;
     int init = 0;  // first term: write instead of add
 };
+// act: 0 none, 1 erf-GELU of the mode (fp32: libm erff; 16-bit: the 1.5e-7 erf), 2 the 1.5e-7 erf regardless of dtype
 hipError_t launch_layernorm(int dtype, const float* x, const float* gamma, const float* beta, long rows, int C, int act,
                             float* out32, void* out16, hipStream_t s, const LnAcc& fa = LnAcc());
 // a state produced by a non-LayerNorm kernel: its 16-bit copy (out16, dtype BF16 / F16) and / or its Featurizer term

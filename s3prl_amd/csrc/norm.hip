@@ -70,10 +70,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
         y.z = (v[i].z - mu) * rs * g.z + bt.z;
         y.w = (v[i].w - mu) * rs * g.w + bt.w;
         if (act) {
-            y.x = gelu_mode<T>(y.x);
-            y.y = gelu_mode<T>(y.y);
-            y.z = gelu_mode<T>(y.z);
-            y.w = gelu_mode<T>(y.w);
+            if (sizeof(typename Cvt<T>::store_t) == 2 || act == 2) gelu4<true>(y.x, y.y, y.z, y.w);
+            else gelu4<false>(y.x, y.y, y.z, y.w);
         }
         if (out32) *(float4*)(out32 + row * C + 4 * ch) = y;
         if (out16) {

@@ -101,6 +101,11 @@ def gather_layers(hs: torch.Tensor, group=None, overlap_events: Optional[list] =
     NLp1, Bs, T, D = hs.shape
     if out is None:
         out = torch.empty((NLp1, world * Bs, T, D), dtype=hs.dtype, device=hs.device)
+    result = out
+    if hs.dtype in (torch.bfloat16, torch.float16):
+        # 16-bit states (s3enc_forward_ex out_dtype): an all-gather only moves bytes, so exchange them as int16 — every
+        # backend supports that, gloo's bfloat16 coverage varies
+        hs, out = hs.view(torch.int16), out.view(torch.int16)
     works = []
     if overlap_events is not None and hs.is_cuda:
         key = hs.device.index
@@ -116,7 +121,7 @@ def gather_layers(hs: torch.Tensor, group=None, overlap_events: Optional[list] =
             works.append(dist.all_gather_into_tensor(out[l], hs[l], group=group, async_op=True))
     for w in works:
         w.wait()
-    return out
+    return result
 
 
 class DataParallelUpstream(torch.nn.Module):

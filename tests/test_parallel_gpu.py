@@ -64,3 +64,62 @@ def test_two_ranks_on_the_gpu_reproduce_the_full_batch(lengths):
         assert np.array_equal(a, b)  # same kernels, same per-row arithmetic: bit-exact
     total = float(sum(np.abs(h.astype(np.float64)).sum() for h in got["dp"]))
     assert abs(got["sum"] - total) / total < 1e-9  # rank 1 holds the same gathered result
+
+
+def _worker_modes(rank, world, port, lengths, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from s3prl_amd.parallel import encode_data_parallel, featurized_data_parallel
+    from s3prl_amd.synth import named_config, synth_wavs, synth_weights
+    from s3prl_amd.upstream.wavlm.expert import UpstreamExpert
+
+    cfg = named_config("tiny_wavlm_large")  # pre-LN, gated relative-position bias
+    weights = synth_weights(cfg, 8)
+    wavs = [torch.from_numpy(w).cuda() for w in synth_wavs(lengths, 18)]
+    lw = torch.softmax(torch.linspace(-1, 1, cfg.encoder_layers + 1), 0).tolist()
+    # (1) Featurizer epilogue inside the encoder + ONE all-gather
+    fp32 = UpstreamExpert.from_weights(cfg, weights)
+    feat = featurized_data_parallel(fp32, lw, wavs, normalize=True)
+    ref = fp32.encode_featurized(wavs, lw, True) if rank == 0 else None
+    # (2) 16-bit states: half the bytes through the exchange
+    bf = UpstreamExpert.from_weights(cfg, weights, dtype="bf16")
+    hs16 = encode_data_parallel(lambda mine, n_max: bf.encode(mine, n_max=n_max, out_dtype="bf16"), wavs)
+    full16 = bf.encode(wavs, out_dtype="bf16") if rank == 0 else None
+    torch.cuda.synchronize()
+    if rank == 0:
+        ret.put(("feat", feat.cpu().numpy(), ref.cpu().numpy()))
+        ret.put(("hs16", torch.stack(hs16).float().cpu().numpy(), full16.float().cpu().numpy()))
+    else:
+        ret.put(("sum", float(feat.double().abs().sum()), float(torch.stack(hs16).double().abs().sum())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_featurized_and_16bit_exchange():
+    """The reduced-exchange modes of the data-parallel path: the weighted sum computed by the encoder's own
+    epilogue on each shard + one (B, T, D) all-gather, and 16-bit states through the per-layer gathers — both must equal
+    the single-process result bit for bit (same kernels, same rows; every batch coupling goes through the global n_max)."""
+    import torch.multiprocessing as mp
+
+    lengths = [4000, 2345, 3111]
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = 32500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker_modes, args=(r, 2, port, lengths, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [ret.get(timeout=300) for _ in range(3)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    by = {g[0]: g[1:] for g in got}
+    assert np.array_equal(by["feat"][0], by["feat"][1])
+    assert np.array_equal(by["hs16"][0], by["hs16"][1])
+    assert abs(by["sum"][0] - float(np.abs(by["feat"][0].astype(np.float64)).sum())) < 1e-6 * by["sum"][0]
+    assert abs(by["sum"][1] - float(np.abs(by["hs16"][0].astype(np.float64)).sum())) < 1e-6 * by["sum"][1]
