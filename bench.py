@@ -160,6 +160,9 @@ def dry_run(args, world, rank):
 
 def main():
     args = parse_args()
+    # multi-process GPU work needs dmabuf IPC (the host driver has no legacy IPC): must be in the environment before the
+    # HIP runtime initialises, i.e. before torch touches the device
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and args.gpus > 1:
         sys.exit(self_launch(args))

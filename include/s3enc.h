@@ -68,6 +68,9 @@ typedef struct s3enc_config {
     int32_t gru_rel_pos;
     int32_t compute_dtype;                 /* S3ENC_F32 / BF16 / F16 / F32X3 */
     int32_t no_feature_layer_norm;         /* 1: post_extract_proj reads the conv output directly (distiller/model.py:170-176) */
+    int32_t pos_conv_depth;                /* data2vec: > 1 = that many {Conv1d(D, D, max(3, conv_pos / depth), groups) -> LayerNorm(no
+                                            * affine) -> GELU} blocks instead of the single weight-normed conv (wav2vec2_model.py:2995-3023);
+                                            * 0 / 1 = the standard positional conv */
     int32_t pred_heads;                    /* DistilHuBERT: N prediction heads Linear(D, N*D) -> GELU -> SplitLinear(D, N, D)
                                             * (distiller/model.py:155-161, module.py:55-90); 0 otherwise */
 } s3enc_config;

@@ -110,14 +110,12 @@ def fold_weight_norm(g: np.ndarray, v: np.ndarray) -> np.ndarray:
     return (g.astype(np.float64) * v.astype(np.float64) / norm).astype(v.dtype)
 
 
-def pos_conv(cfg, W: Dict[str, np.ndarray], x_btd: np.ndarray) -> np.ndarray:
-    """``make_conv_pos`` + ``SamePad`` + GELU (wav2vec2_model.py:2937-2953,1797-1808):
-    grouped Conv1d(D, D, k, padding=k//2, groups=g), drop the last frame when k is even, GELU."""
+def grouped_conv_same(x_btd: np.ndarray, w: np.ndarray, bias: np.ndarray, G: int) -> np.ndarray:
+    """Conv1d(D, D, K, padding=K//2, groups=G) + SamePad (drop the last frame when K is even) on channel-last data
+    (wav2vec2_model.py:2941-2951,1797-1808)."""
     B, T, D = x_btd.shape
-    K, G = cfg.conv_pos, cfg.conv_pos_groups
+    K = w.shape[2]
     Dg = D // G
-    w = fold_weight_norm(W["encoder.pos_conv.0.weight_g"], W["encoder.pos_conv.0.weight_v"]).astype(x_btd.dtype)
-    bias = W["encoder.pos_conv.0.bias"].astype(x_btd.dtype)
     pad = K // 2
     xp = np.zeros((B, T + 2 * pad, D), dtype=x_btd.dtype)
     xp[:, pad:pad + T] = x_btd
@@ -134,7 +132,23 @@ def pos_conv(cfg, W: Dict[str, np.ndarray], x_btd: np.ndarray) -> np.ndarray:
     out = out + bias
     if K % 2 == 0:
         out = out[:, :-1]  # SamePad
-    return gelu(out)
+    return out
+
+
+def pos_conv(cfg, W: Dict[str, np.ndarray], x_btd: np.ndarray) -> np.ndarray:
+    """``make_conv_pos`` + ``SamePad`` + GELU (wav2vec2_model.py:2937-2953,1797-1808): weight-normed grouped
+    Conv1d(D, D, k, padding=k//2, groups=g), drop the last frame when k is even, GELU.  data2vec (``pos_conv_depth`` > 1,
+    :2995-3023): a stack of {Conv1d(k = max(3, conv_pos // depth)) -> SamePad -> LayerNorm(no affine) -> GELU}."""
+    G = cfg.conv_pos_groups
+    if getattr(cfg, "pos_conv_depth", 1) > 1:
+        y = x_btd
+        for i in range(cfg.pos_conv_depth):
+            y = grouped_conv_same(y, W[f"encoder.pos_conv.{i}.0.weight"].astype(x_btd.dtype),
+                                  W[f"encoder.pos_conv.{i}.0.bias"].astype(x_btd.dtype), G)
+            y = gelu(layer_norm(y, None, None))
+        return y
+    w = fold_weight_norm(W["encoder.pos_conv.0.weight_g"], W["encoder.pos_conv.0.weight_v"]).astype(x_btd.dtype)
+    return gelu(grouped_conv_same(x_btd, w, W["encoder.pos_conv.0.bias"].astype(x_btd.dtype), G))
 
 
 # ------------------------------------------------------------------------------------------------

@@ -30,8 +30,9 @@ def prepare(cfg, weights: Dict[str, np.ndarray], dtype=torch.float32) -> Dict[st
     """state_dict -> torch tensors; folds ``weight_norm(dim=2)`` of the positional conv
     (wav2vec2_model.py:2950; WavLM.py:548) once, like the parametrisation does on every forward."""
     W = {k: _t(weights, k, dtype) for k in weights}
-    g, v = W["encoder.pos_conv.0.weight_g"].double(), W["encoder.pos_conv.0.weight_v"].double()
-    W["encoder.pos_conv.0.weight"] = (g * v / v.pow(2).sum(dim=(0, 1), keepdim=True).sqrt()).to(dtype)
+    if "encoder.pos_conv.0.weight_g" in W:
+        g, v = W["encoder.pos_conv.0.weight_g"].double(), W["encoder.pos_conv.0.weight_v"].double()
+        W["encoder.pos_conv.0.weight"] = (g * v / v.pow(2).sum(dim=(0, 1), keepdim=True).sqrt()).to(dtype)
     return W
 
 
@@ -142,12 +143,17 @@ def forward(cfg, W: Dict[str, torch.Tensor], wavs: List[torch.Tensor], n_max: Op
     x = F.linear(x, W["post_extract_proj.weight"], W["post_extract_proj.bias"])
     if use_mask:
         x = x.masked_fill(kpm.unsqueeze(-1), 0.0)  # index_put(x, padding_mask, 0) :3061-3062
-    K = cfg.conv_pos
-    xc = F.conv1d(x.transpose(1, 2), W["encoder.pos_conv.0.weight"], W["encoder.pos_conv.0.bias"], padding=K // 2,
-                  groups=cfg.conv_pos_groups)
-    if K % 2 == 0:
-        xc = xc[:, :, :-1]  # SamePad :1797-1808
-    x = x + F.gelu(xc).transpose(1, 2)
+    xc = x.transpose(1, 2)
+    for i in range(max(1, getattr(cfg, "pos_conv_depth", 1))):  # data2vec: conv -> SamePad -> LayerNorm -> GELU blocks :2995-3023
+        K = W[f"encoder.pos_conv.{i}.0.weight"].shape[-1]
+        xc = F.conv1d(xc, W[f"encoder.pos_conv.{i}.0.weight"], W[f"encoder.pos_conv.{i}.0.bias"], padding=K // 2,
+                      groups=cfg.conv_pos_groups)
+        if K % 2 == 0:
+            xc = xc[:, :, :-1]  # SamePad :1797-1808
+        if getattr(cfg, "pos_conv_depth", 1) > 1:
+            xc = F.layer_norm(xc.transpose(1, 2), (xc.shape[1],)).transpose(1, 2)
+        xc = F.gelu(xc)
+    x = x + xc.transpose(1, 2)
     if not cfg.layer_norm_first:
         x = F.layer_norm(x, (x.shape[-1],), W["encoder.layer_norm.weight"], W["encoder.layer_norm.bias"], 1e-5)
     pos_bias = rel_pos_bias(cfg, W, T).to(dt) if (cfg.family == "wavlm" and cfg.relative_position_embedding) else None

@@ -78,7 +78,7 @@ def save_checkpoint(path: str, cfg: EncoderConfig, weights: Dict[str, np.ndarray
         extractor_mode=cfg.extractor_mode, conv_bias=cfg.conv_bias, encoder_layers=cfg.encoder_layers,
         encoder_embed_dim=cfg.encoder_embed_dim, encoder_ffn_embed_dim=cfg.encoder_ffn_embed_dim,
         encoder_attention_heads=cfg.encoder_attention_heads, layer_norm_first=cfg.layer_norm_first,
-        conv_pos=cfg.conv_pos, conv_pos_groups=cfg.conv_pos_groups, activation_fn="gelu",
+        conv_pos=cfg.conv_pos, conv_pos_groups=cfg.conv_pos_groups, activation_fn="gelu", pos_conv_depth=cfg.pos_conv_depth,
         conv_feature_layers=str([tuple(t) for t in cfg.conv_layers]),
     )
     if cfg.family == "distiller":

@@ -79,6 +79,9 @@ class EncoderConfig:
     # post_extract_proj, and ``pred_heads`` prediction heads (Linear -> GELU -> SplitLinear) on the last layer
     feature_layer_norm: bool = True
     pred_heads: int = 0
+    # data2vec-audio (upstream/data2vec, wav2vec2_model.py:2995-3023): pos_conv_depth > 1 replaces the weight-normed
+    # positional conv by that many {Conv1d(k = max(3, conv_pos // depth), groups) -> LayerNorm(no affine) -> GELU} blocks
+    pos_conv_depth: int = 1
 
     # ---- derived -------------------------------------------------------------------------
     @property
@@ -88,6 +91,10 @@ class EncoderConfig:
     @property
     def head_dim(self) -> int:
         return self.encoder_embed_dim // self.encoder_attention_heads
+
+    @property
+    def pos_conv_kernel(self) -> int:
+        return self.conv_pos if self.pos_conv_depth <= 1 else max(3, self.conv_pos // self.pos_conv_depth)
 
     @property
     def num_hidden_states(self) -> int:
@@ -169,8 +176,9 @@ def config_from_dicts(family: str, model_cfg: Dict, task_cfg: Dict | None = None
         raise ValueError(f"only activation_fn='gelu' is on the hot path, got {act!r}")
     if str(model_cfg.get("layer_type", "transformer")).endswith("conformer"):
         raise ValueError("conformer layers are out of scope (SURVEY §2.1)")
-    if int(model_cfg.get("pos_conv_depth", 1)) != 1:
-        raise ValueError("pos_conv_depth > 1 (data2vec) is out of scope (SURVEY §8f)")
+    cfg.pos_conv_depth = int(model_cfg.get("pos_conv_depth", 1) or 1)
+    if cfg.pos_conv_depth > 1 and family != "wav2vec2":
+        raise ValueError("pos_conv_depth > 1 is the data2vec-audio encoder (wav2vec2 family)")
     if family == "wavlm":
         for k in _WAVLM_KEYS:
             if k in model_cfg:

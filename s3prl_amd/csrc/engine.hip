@@ -224,6 +224,12 @@ struct s3enc_encoder {
     std::vector<LayerW> layers;
     DevBuf rel_table;  // WavLM: [H][2R+1], entry (h, rel + R), R = max_distance (the bucket saturates there)
     int rel_R = 0;
+    // data2vec positional-conv stack (cfg.pos_conv_depth > 1): per block the packed conv weight + bias; pos_k = the kernel
+    // width as packed (zero taps appended so that the 16-bit implicit GEMM's k axis is a multiple of 128), pos_pad = the
+    // real kernel's K / 2; ones / zeros = the affine of LayerNorm(elementwise_affine=False)
+    std::vector<DevBuf> pos_ws, pos_bs;
+    int pos_k = 0, pos_pad = 0;
+    DevBuf ones, zeros;
     DevBuf head_w1, head_b1, head_w2, head_b2, head_w13, head_w23;  // DistilHuBERT prediction heads (+ S3ENC_F32X3 images)
     DevBuf wsum_part;  // persistent partials of s3enc_weighted_sum_backward
 
@@ -402,6 +408,8 @@ int check_config(const s3enc_config& c) {
     if (c.rel_pos && (c.num_buckets < 4 || c.max_distance <= c.num_buckets / 4))
         return fail("config: bad num_buckets / max_distance");
     if (c.rel_pos && c.max_distance > 8192) return fail("config: max_distance > 8192");
+    if (c.pos_conv_depth < 0 || c.pos_conv_depth > 16) return fail("config: pos_conv_depth out of range");
+    if (c.pos_conv_depth > 1 && c.family != S3ENC_WAV2VEC2) return fail("config: pos_conv_depth > 1 is the data2vec-audio encoder (wav2vec2 family)");
     return 0;
 }
 
@@ -502,7 +510,37 @@ int s3enc_create(const s3enc_config* cfg, const s3enc_tensor* tensors, int32_t n
     UP(upload_f32(e->proj_b, t));
 
     // ---- positional conv: fold weight_norm(dim=2), then pack for the kernel of the compute dtype ----
-    {
+    if (c.pos_conv_depth > 1) {
+        // data2vec (wav2vec2_model.py:2995-3023): plain grouped convs of width max(3, conv_pos / depth), no weight_norm
+        const int G = c.conv_pos_groups, Dg = D / G;
+        int k = c.conv_pos / c.pos_conv_depth;
+        k = k < 3 ? 3 : k;
+        const bool k16 = e->dtype != F32 || e->x3;  // the implicit-GEMM kernel: even K with K * Dg a multiple of 128
+        int kp = k;
+        if (k16)
+            while ((kp & 1) || ((long)kp * Dg) % 128) ++kp;
+        e->pos_k = kp;
+        e->pos_pad = k / 2;
+        e->pos_ws.resize(c.pos_conv_depth);
+        e->pos_bs.resize(c.pos_conv_depth);
+        for (int i = 0; i < c.pos_conv_depth; ++i) {
+            const std::string p = "encoder.pos_conv." + std::to_string(i) + ".0";
+            std::vector<float> w, wp((size_t)D * Dg * kp, 0.f);
+            GET(p + ".weight", (long)D * Dg * k, w);
+            for (long r = 0; r < (long)D * Dg; ++r)
+                for (int j = 0; j < k; ++j) wp[r * kp + j] = w[r * k + j];
+            if (e->x3) {
+                UP(upload_posconv_x3(e->pos_ws[i], wp, D, G, kp));
+            } else {
+                pack_posconv(wp, D, G, kp, e->dtype, t2);
+                UP(upload_cvt(e->pos_ws[i], t2, e->dtype));
+            }
+            GET(p + ".bias", D, t);
+            UP(upload_f32(e->pos_bs[i], t));
+        }
+        UP(upload_f32(e->ones, std::vector<float>(D, 1.f)));
+        UP(upload_f32(e->zeros, std::vector<float>(D, 0.f)));
+    } else {
         const int K = c.conv_pos, G = c.conv_pos_groups, Dg = D / G;
         std::vector<float> g, v;
         GET("encoder.pos_conv.0.weight_g", K, g);
@@ -965,14 +1003,38 @@ int forward_impl(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
         p.D = D;
         p.G = c.conv_pos_groups;
         p.K = c.conv_pos;
-        {
-            Prof pr(e, st, "posconv", 2.0 * M * D * (D / p.G) * p.K, (double)M * D * 8 + (double)D * (D / p.G) * p.K * 4);
-            if (e->x3) {
-                p.w = e->pos_w3.p;
-                HIP_TRY(launch_posconv16(3, p, st));
-            } else {
-                HIP_TRY(dt == F32 ? launch_posconv(p, st) : launch_posconv16(dt, p, st));
+        auto run_conv = [&](PosConvParams& q) -> hipError_t {
+            if (e->x3) return launch_posconv16(3, q, st);
+            return dt == F32 ? launch_posconv(q, st) : launch_posconv16(dt, q, st);
+        };
+        if (c.pos_conv_depth > 1) {
+            // data2vec: x + block_n(...block_1(x)), block = conv -> LayerNorm(no affine) -> GELU (wav2vec2_model.py:2999-3017)
+            const float* cur_in = xproj;
+            const int gelu_act = (dt != F32 || e->x3) ? 2 : 1;
+            for (int i = 0; i < c.pos_conv_depth; ++i) {
+                p.x = cur_in;
+                p.w = e->pos_ws[i].p;
+                p.bias = (const float*)e->pos_bs[i].p;
+                p.out = (float*)tmp1;
+                p.K = e->pos_k;
+                p.pad = e->pos_pad;
+                p.plain = 1;
+                {
+                    Prof pr(e, st, "posconv", 2.0 * M * D * (D / p.G) * (2 * e->pos_pad + 1), (double)M * D * 8);
+                    HIP_TRY(run_conv(p));
+                }
+                Prof pr(e, st, "layernorm:posconv", 0, (double)M * D * 8);
+                HIP_TRY(launch_layernorm(F32, (const float*)tmp1, (const float*)e->ones.p, (const float*)e->zeros.p, M, D, gelu_act,
+                                         (float*)tmp2, nullptr, st));
+                cur_in = (const float*)tmp2;
             }
+            Prof pr(e, st, "residual_add", 0, (double)M * D * 12);
+            HIP_TRY(launch_add(xproj, (const float*)tmp2, pc_out, M * D, st));
+            p.out = pc_out;
+        } else {
+            Prof pr(e, st, "posconv", 2.0 * M * D * (D / p.G) * p.K, (double)M * D * 8 + (double)D * (D / p.G) * p.K * 4);
+            if (e->x3) p.w = e->pos_w3.p;
+            HIP_TRY(run_conv(p));
         }
         e->taps["posconv"] = {p.out, M * D, F32};
         if (prel) {

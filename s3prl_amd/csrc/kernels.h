@@ -123,6 +123,8 @@ struct PosConvParams {
     const float* bias;  // [D]
     float* out;         // (B, T, D) fp32 = x + gelu(conv(x) + bias)
     int B, T, D, G, K;
+    int pad = -1;       // left zero padding in frames; -1 = K / 2 (a K padded with zero taps keeps the real kernel's K / 2)
+    int plain = 0;      // 1: out = conv(x) + bias only (data2vec's conv -> LayerNorm -> GELU stack, wav2vec2_model.py:2999-3017)
 };
 hipError_t launch_posconv(const PosConvParams& p, hipStream_t s);
 // 16-bit operand modes: p.w = 16-bit pack [G][Dg][K*Dg] with k = tap*Dg + ci; x / out / bias fp32

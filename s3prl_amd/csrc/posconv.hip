@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void posconv_kernel(PosConvParams p) {
     const int t0 = blockIdx.x * PC_TM;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, kk = lane >> 4;
-    const int pad = K / 2;
+    const int pad = p.pad >= 0 ? p.pad : K / 2;
 
     const float* xg = p.x + (long)b * p.T * p.D + g * DG;
     for (int idx = tid; idx < rows * (DG / 4); idx += 256) {
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void posconv_kernel(PosConvParams p) {
             const int t = t0 + wave * 16 + 4 * kk + r;
             if (t < p.T) {
                 const long o = ((long)b * p.T + t) * p.D + c;
-                p.out[o] = p.x[o] + gelu_erf(acc[n][r] + bias);
+                p.out[o] = p.plain ? acc[n][r] + bias : p.x[o] + gelu_erf(acc[n][r] + bias);
             }
         }
     }
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void posconv16_kernel(PosConvParams p) {
     const int t0 = blockIdx.x * TMF;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, kgrp = lane >> 4;
-    const int pad = K / 2;
+    const int pad = p.pad >= 0 ? p.pad : K / 2;
     const long Ktot = (long)K * DG;
 
     // ---- W stage loader: piece e = (row n, chunk c); LDS slot of chunk c in row n is c ^ (n & 15).
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256) void posconv16_kernel(PosConvParams p) {
                 if (t < p.T) {
                     const long o = ((long)b * p.T + t) * p.D + c;
                     const float y = acc[m][n][r] + bias;
-                    p.out[o] = p.x[o] + gelu_fast(y);
+                    p.out[o] = p.plain ? y : p.x[o] + gelu_fast(y);
                 }
             }
     }

@@ -8,6 +8,7 @@ from .upstream.wav2vec2.hubconf import *  # noqa: F401,F403
 from .upstream.wavlm.hubconf import *  # noqa: F401,F403
 from .upstream.unispeech_sat.hubconf import *  # noqa: F401,F403
 from .upstream.distiller.hubconf import *  # noqa: F401,F403
+from .upstream.data2vec.hubconf import *  # noqa: F401,F403
 from .upstream.baseline.hubconf import *  # noqa: F401,F403
 
 

@@ -103,9 +103,9 @@ def gather_layers(hs: torch.Tensor, group=None, overlap_events: Optional[list] =
         out = torch.empty((NLp1, world * Bs, T, D), dtype=hs.dtype, device=hs.device)
     result = out
     if hs.dtype in (torch.bfloat16, torch.float16):
-        # 16-bit states (s3enc_forward_ex out_dtype): an all-gather only moves bytes, so exchange them as int16 — every
-        # backend supports that, gloo's bfloat16 coverage varies
-        hs, out = hs.view(torch.int16), out.view(torch.int16)
+        # 16-bit states (s3enc_forward_ex out_dtype): an all-gather only moves bytes, so exchange them as uint8 — the one
+        # element type every backend supports (gloo rejects bfloat16 and int16 on device tensors)
+        hs, out = hs.view(torch.uint8), out.view(torch.uint8)
     works = []
     if overlap_events is not None and hs.is_cuda:
         key = hs.device.index

@@ -40,9 +40,14 @@ def param_shapes(cfg: EncoderConfig) -> Dict[str, tuple]:
         s["layer_norm.bias"] = (C,)
     s["post_extract_proj.weight"] = (D, C)
     s["post_extract_proj.bias"] = (D,)
-    s["encoder.pos_conv.0.bias"] = (D,)
-    s["encoder.pos_conv.0.weight_g"] = (1, 1, cfg.conv_pos)
-    s["encoder.pos_conv.0.weight_v"] = (D, D // cfg.conv_pos_groups, cfg.conv_pos)
+    if cfg.pos_conv_depth > 1:  # data2vec: plain convs, no weight_norm (wav2vec2_model.py:3001-3007)
+        for i in range(cfg.pos_conv_depth):
+            s[f"encoder.pos_conv.{i}.0.weight"] = (D, D // cfg.conv_pos_groups, cfg.pos_conv_kernel)
+            s[f"encoder.pos_conv.{i}.0.bias"] = (D,)
+    else:
+        s["encoder.pos_conv.0.bias"] = (D,)
+        s["encoder.pos_conv.0.weight_g"] = (1, 1, cfg.conv_pos)
+        s["encoder.pos_conv.0.weight_v"] = (D, D // cfg.conv_pos_groups, cfg.conv_pos)
     s["encoder.layer_norm.weight"] = (D,)
     s["encoder.layer_norm.bias"] = (D,)
     for l in range(cfg.encoder_layers):
@@ -94,6 +99,8 @@ def synth_weights(cfg: EncoderConfig, seed: int = 0) -> Dict[str, np.ndarray]:
             w = 1.0 + 0.1 * rng.standard_normal(shape)
         elif leaf == "bias":
             w = 0.05 * rng.standard_normal(shape)
+        elif "pos_conv" in name and leaf == "weight":  # data2vec conv block (out, in/g, k)
+            w = rng.standard_normal(shape) * np.sqrt(2.0 / (shape[1] * shape[2]))
         elif "conv_layers" in name:  # (out, in, k): keep unit variance through GELU (gain ~ sqrt(2.5))
             fan_in = shape[1] * shape[2]
             w = rng.standard_normal(shape) * np.sqrt(2.5 / fan_in)
@@ -151,6 +158,9 @@ def named_config(name: str) -> EncoderConfig:
         "distilhubert": dict(family="distiller", encoder_layers=2, feature_layer_norm=False, pred_heads=3),
         "tiny_distiller": dict(family="distiller", feature_layer_norm=False, pred_heads=3, **{**tiny, "encoder_layers": 2}),
         "tiny_wavlm_norel": dict(family="wavlm", **tiny),
+        "data2vec_base": dict(family="wav2vec2", extractor_mode="layer_norm", conv_pos=95, pos_conv_depth=5, normalize=True),
+        "tiny_data2vec": dict(family="wav2vec2", **{**tiny, "extractor_mode": "layer_norm", "conv_pos": 15,
+                                                   "pos_conv_depth": 3, "normalize": True}),
         "tiny_hubert": dict(family="hubert", **tiny),
         "tiny_wav2vec2": dict(family="wav2vec2", **tiny),
         "tiny_hubert_large": dict(family="hubert", **{**tiny, "extractor_mode": "layer_norm",

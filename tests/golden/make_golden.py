@@ -59,6 +59,8 @@ CASES = {
     "unispeech_sat_base_pseudo": ("wavlm_base", 1, 29, [23456, 16000], (4, 8), 0.0, 1.0, {"expert": "unispeech_sat"}),
     "tiny_distiller_pad": ("tiny_distiller", 11, 30, [4000, 2345, 3111, 800], (1, 1), 0.0, 1.0),
     "distilhubert_pseudo": ("distilhubert", 0, 31, [23456, 16000], (4, 8), 0.0, 1.0),
+    "tiny_data2vec_pad": ("tiny_data2vec", 12, 32, [4000, 2345, 3111], (1, 1), 0.0, 1.0),
+    "data2vec_base_pseudo": ("data2vec_base", 0, 33, [23456, 16000], (4, 8), 0.0, 1.0),
     # wav2vec2 feature_selection (wav2vec2/expert.py:81-93)
     "tiny_wav2vec2_fslayers": ("tiny_wav2vec2", 3, 13, [4000, 2345, 3111, 800], (1, 1), 0.0, 1.0,
                                {"selection": "fairseq_layers"}),
@@ -107,6 +109,19 @@ def build_reference_expert(cfg, weights, tmpdir, extras=None):
         _load(model, weights)
         torch.save({"task_cfg": dataclasses.asdict(tc), "model_cfg": dataclasses.asdict(mc),
                     "model_weight": model.state_dict(), "dictionaries_symbols": [["a"] * 8]}, path)
+    elif cfg.family == "wav2vec2" and cfg.pos_conv_depth > 1:  # data2vec-audio (upstream/data2vec)
+        from s3prl.upstream.data2vec.data2vec_model import Data2VecAudioConfig, Data2VecAudioModel
+        from s3prl.upstream.data2vec.expert import UpstreamExpert
+        from s3prl.upstream.wav2vec2.wav2vec2_model import AudioPretrainingConfig
+
+        mc = Data2VecAudioConfig(pos_conv_depth=cfg.pos_conv_depth, **common)
+        tc = AudioPretrainingConfig(normalize=cfg.normalize)
+        model = Data2VecAudioModel(mc)
+        model.remove_pretraining_modules()
+        _load(model, weights)
+        sd = dict(model.state_dict())
+        sd["_ema"] = {}  # load_converted_model deletes this key (data2vec/convert.py:49)
+        torch.save({"task_cfg": dataclasses.asdict(tc), "model_cfg": dataclasses.asdict(mc), "model_weight": sd}, path)
     elif cfg.family == "wav2vec2":
         from s3prl.upstream.wav2vec2.wav2vec2_model import AudioPretrainingConfig, Wav2Vec2Config, Wav2Vec2Model
         from s3prl.upstream.wav2vec2.expert import UpstreamExpert

@@ -14,7 +14,7 @@ def test_conv_layer_spec_parser():
         parse_conv_layers("__import__('os').system('true')")
 
 
-@pytest.mark.parametrize("name", ["tiny_hubert", "tiny_wav2vec2_large", "tiny_wavlm_large"])
+@pytest.mark.parametrize("name", ["tiny_hubert", "tiny_wav2vec2_large", "tiny_wavlm_large", "tiny_distiller", "tiny_data2vec"])
 def test_checkpoint_roundtrip(tmp_path, name):
     from s3prl_amd.ckpt import load_checkpoint, save_checkpoint
     from s3prl_amd.synth import named_config, synth_weights
@@ -43,8 +43,9 @@ def test_hub_entries_follow_the_reference_naming():
     import s3prl_amd.hub as hub
 
     names = hub.options()
-    for fam in ("hubert", "wav2vec2", "wavlm", "unispeech_sat"):
+    for fam in ("hubert", "wav2vec2", "wavlm", "unispeech_sat", "data2vec"):
         assert fam in names and f"{fam}_local" in names and f"{fam}_custom" in names
+    assert "distiller_local" in names and "distilhubert" in names
     assert all(not n.endswith("_local") for n in hub.options(only_registered_ckpt=True))
     for n in ("fbank", "fbank_no_cmvn", "baseline", "baseline_local"):
         assert n in names

@@ -29,7 +29,7 @@ def _dev(wavs):
 CASES = [("tiny_hubert_pad", None), ("tiny_hubert_large_pad", None), ("tiny_wavlm_large_pad", None), ("tiny_wavlm_pad", None),
          ("tiny_wav2vec2_pad", "fairseq_layers"), ("tiny_wav2vec2_large_pad", "fairseq_layers"),
          ("tiny_wav2vec2_pad", "fairseq_layers_before_residual"), ("tiny_wav2vec2_large_pad", "fairseq_layers_before_residual"),
-         ("tiny_distiller_pad", None), ("hubert_base_pseudo", None), ("wavlm_large_pseudo", None)]
+         ("tiny_distiller_pad", None), ("hubert_base_pseudo", None), ("wavlm_large_pseudo", None), ("tiny_data2vec_pad", None)]
 
 
 @pytest.mark.parametrize("normalize", [False, True])

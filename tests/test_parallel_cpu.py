@@ -127,3 +127,42 @@ def test_gloo_featurize_before_gather_equals_full_batch():
     for r in range(world):
         assert results[r].shape == ref.shape
         assert O.rel_err(results[r], ref) < 1e-5
+
+
+def _worker_16(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from s3prl_amd.parallel import gather_layers
+
+    out = {}
+    for dt in (torch.bfloat16, torch.float16):
+        hs = (torch.arange(3 * 2 * 4 * 8, dtype=torch.float32).reshape(3, 2, 4, 8) * (rank + 1) / 64).to(dt)
+        g = gather_layers(hs)
+        out[str(dt)] = (g.dtype == dt, tuple(g.shape), g.float())
+    ret.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_gather_of_16bit_states_moves_bytes():
+    """16-bit states (s3enc_forward_ex out_dtype) go through the per-layer gathers as raw bytes: same values, same dtype,
+    rank-major order."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker_16, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(ret.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    base = torch.arange(3 * 2 * 4 * 8, dtype=torch.float32).reshape(3, 2, 4, 8) / 64
+    for r in range(world):
+        for dt in (torch.bfloat16, torch.float16):
+            ok, shape, g = results[r][str(dt)]
+            assert ok and shape == (3, 4, 4, 8)
+            assert torch.equal(g[:, :2], base.to(dt).float()) and torch.equal(g[:, 2:], (base * 2).to(dt).float())

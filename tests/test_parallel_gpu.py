@@ -67,6 +67,16 @@ def test_two_ranks_on_the_gpu_reproduce_the_full_batch(lengths):
 
 
 def _worker_modes(rank, world, port, lengths, ret):
+    try:
+        _worker_modes_body(rank, world, port, lengths, ret)
+    except Exception:  # a crashed rank must not leave the parent (and the GPU box) waiting for its timeout
+        import traceback
+
+        ret.put(("error", traceback.format_exc()))
+        os._exit(1)
+
+
+def _worker_modes_body(rank, world, port, lengths, ret):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -114,7 +124,14 @@ def test_two_ranks_featurized_and_16bit_exchange():
     procs = [ctx.Process(target=_worker_modes, args=(r, 2, port, lengths, ret)) for r in range(2)]
     for p in procs:
         p.start()
-    got = [ret.get(timeout=300) for _ in range(3)]
+    got = []
+    for _ in range(3):
+        item = ret.get(timeout=180)
+        if item[0] == "error":
+            for p in procs:
+                p.kill()
+            pytest.fail(item[1])
+        got.append(item)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
