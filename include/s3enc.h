@@ -71,6 +71,8 @@ typedef struct s3enc_config {
     int32_t pos_conv_depth;                /* data2vec: > 1 = that many {Conv1d(D, D, max(3, conv_pos / depth), groups) -> LayerNorm(no
                                             * affine) -> GELU} blocks instead of the single weight-normed conv (wav2vec2_model.py:2995-3023);
                                             * 0 / 1 = the standard positional conv */
+    float wav_norm_eps;                    /* eps of the waveform normalisation; 0 = 1e-5 (F.layer_norm, hubert/expert.py:57-58);
+                                            * Hugging Face's Wav2Vec2FeatureExtractor uses 1e-7 (upstream/hf_hubert/expert.py:30-37) */
     int32_t pred_heads;                    /* DistilHuBERT: N prediction heads Linear(D, N*D) -> GELU -> SplitLinear(D, N, D)
                                             * (distiller/model.py:155-161, module.py:55-90); 0 otherwise */
 } s3enc_config;

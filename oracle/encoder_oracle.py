@@ -45,10 +45,12 @@ def layer_norm(x: np.ndarray, w: Optional[np.ndarray], b: Optional[np.ndarray]) 
     return y.astype(x.dtype)
 
 
-def wav_normalize(wav: np.ndarray) -> np.ndarray:
-    """``F.layer_norm(wav, wav.shape)`` per utterance before padding
-    (hubert/expert.py:57-58, wavlm/expert.py:72-73, wav2vec2/expert.py:68)."""
-    return layer_norm(wav[None, :], None, None)[0]
+def wav_normalize(wav: np.ndarray, eps: float = EPS) -> np.ndarray:
+    """``F.layer_norm(wav, wav.shape)`` per utterance before padding (hubert/expert.py:57-58, wavlm/expert.py:72-73,
+    wav2vec2/expert.py:68); ``eps`` 1e-7 = Hugging Face's ``zero_mean_unit_var_norm`` (hf_hubert/expert.py:30-37)."""
+    mu = wav.mean()
+    xc = wav - mu
+    return (xc / np.sqrt((xc * xc).mean() + eps)).astype(wav.dtype)
 
 
 def group_norm_per_channel(x_btc: np.ndarray, w: np.ndarray, b: np.ndarray) -> np.ndarray:
@@ -269,7 +271,7 @@ def forward(cfg, weights: Dict[str, np.ndarray], wavs: List[np.ndarray], dtype=n
     for b, w in enumerate(wavs):
         w = w.astype(dt)
         if cfg.normalize:
-            w = wav_normalize(w)
+            w = wav_normalize(w, getattr(cfg, "wav_norm_eps", EPS))
         padded[b, :lens[b]] = w
 
     feats = feature_extractor(cfg, W, padded, taps)  # (B,T,C)

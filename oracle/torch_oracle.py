@@ -125,8 +125,8 @@ def forward(cfg, W: Dict[str, torch.Tensor], wavs: List[torch.Tensor], n_max: Op
     lens = [int(w.numel()) for w in wavs]
     n_max = n_max or max(lens)
     B = len(wavs)
-    if cfg.normalize:
-        wavs = [F.layer_norm(w.to(dt), w.shape) for w in wavs]  # hubert/expert.py:57-58
+    if cfg.normalize:  # hubert/expert.py:57-58 (eps 1e-5); Hugging Face's feature extractor: 1e-7
+        wavs = [F.layer_norm(w.to(dt), w.shape, eps=getattr(cfg, "wav_norm_eps", 1e-5)) for w in wavs]
     padded = torch.zeros(B, n_max, dtype=dt)
     for b, w in enumerate(wavs):
         padded[b, : lens[b]] = w.to(dt)
@@ -144,13 +144,14 @@ def forward(cfg, W: Dict[str, torch.Tensor], wavs: List[torch.Tensor], n_max: Op
     if use_mask:
         x = x.masked_fill(kpm.unsqueeze(-1), 0.0)  # index_put(x, padding_mask, 0) :3061-3062
     xc = x.transpose(1, 2)
-    for i in range(max(1, getattr(cfg, "pos_conv_depth", 1))):  # data2vec: conv -> SamePad -> LayerNorm -> GELU blocks :2995-3023
-        K = W[f"encoder.pos_conv.{i}.0.weight"].shape[-1]
-        xc = F.conv1d(xc, W[f"encoder.pos_conv.{i}.0.weight"], W[f"encoder.pos_conv.{i}.0.bias"], padding=K // 2,
-                      groups=cfg.conv_pos_groups)
+    depth = getattr(cfg, "pos_conv_depth", 1)
+    for i in range(max(1, depth)):  # data2vec (depth > 1): conv -> SamePad -> LayerNorm -> GELU blocks :2995-3023
+        name = f"encoder.pos_conv.{i}.0" if depth > 1 else "encoder.pos_conv.0"
+        K = W[f"{name}.weight"].shape[-1]
+        xc = F.conv1d(xc, W[f"{name}.weight"], W[f"{name}.bias"], padding=K // 2, groups=cfg.conv_pos_groups)
         if K % 2 == 0:
             xc = xc[:, :, :-1]  # SamePad :1797-1808
-        if getattr(cfg, "pos_conv_depth", 1) > 1:
+        if depth > 1:
             xc = F.layer_norm(xc.transpose(1, 2), (xc.shape[1],)).transpose(1, 2)
         xc = F.gelu(xc)
     x = x + xc.transpose(1, 2)

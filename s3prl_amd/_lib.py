@@ -31,7 +31,7 @@ class S3Config(C.Structure):
         ("embed_dim", C.c_int32), ("ffn_dim", C.c_int32), ("heads", C.c_int32), ("layer_norm_first", C.c_int32),
         ("conv_pos", C.c_int32), ("conv_pos_groups", C.c_int32), ("normalize", C.c_int32), ("rel_pos", C.c_int32),
         ("num_buckets", C.c_int32), ("max_distance", C.c_int32), ("gru_rel_pos", C.c_int32),
-        ("compute_dtype", C.c_int32), ("no_feature_layer_norm", C.c_int32), ("pos_conv_depth", C.c_int32), ("pred_heads", C.c_int32),
+        ("compute_dtype", C.c_int32), ("no_feature_layer_norm", C.c_int32), ("pos_conv_depth", C.c_int32), ("wav_norm_eps", C.c_float), ("pred_heads", C.c_int32),
     ]
 
 
@@ -159,5 +159,6 @@ def make_config(cfg, dtype: str) -> S3Config:
     c.compute_dtype = DTYPES[dtype]
     c.no_feature_layer_norm = int(not cfg.feature_layer_norm)
     c.pos_conv_depth = int(cfg.pos_conv_depth)
+    c.wav_norm_eps = float(cfg.wav_norm_eps)
     c.pred_heads = int(cfg.pred_heads)
     return c

@@ -82,6 +82,9 @@ class EncoderConfig:
     # data2vec-audio (upstream/data2vec, wav2vec2_model.py:2995-3023): pos_conv_depth > 1 replaces the weight-normed
     # positional conv by that many {Conv1d(k = max(3, conv_pos // depth), groups) -> LayerNorm(no affine) -> GELU} blocks
     pos_conv_depth: int = 1
+    # eps of the per-utterance waveform normalisation: F.layer_norm's 1e-5 in the fairseq experts (hubert/expert.py:57-58),
+    # 1e-7 in Hugging Face's Wav2Vec2FeatureExtractor (hf_hubert / hf_wav2vec2 upstreams)
+    wav_norm_eps: float = 1e-5
 
     # ---- derived -------------------------------------------------------------------------
     @property

@@ -409,6 +409,7 @@ int check_config(const s3enc_config& c) {
         return fail("config: bad num_buckets / max_distance");
     if (c.rel_pos && c.max_distance > 8192) return fail("config: max_distance > 8192");
     if (c.pos_conv_depth < 0 || c.pos_conv_depth > 16) return fail("config: pos_conv_depth out of range");
+    if (!(c.wav_norm_eps >= 0.f) || c.wav_norm_eps > 1.f) return fail("config: wav_norm_eps out of range");
     if (c.pos_conv_depth > 1 && c.family != S3ENC_WAV2VEC2) return fail("config: pos_conv_depth > 1 is the data2vec-audio encoder (wav2vec2 family)");
     return 0;
 }
@@ -883,7 +884,7 @@ int forward_impl(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
     WavTable wt{d_ptrs, d_lens, B, n_max};
     {
         Prof pr(e, st, "wav_stats", 0, 4.0 * B * n_max);
-        HIP_TRY(launch_wav_norm_stats(wt, c.normalize, d_part, d_norm, st));
+        HIP_TRY(launch_wav_norm_stats(wt, c.normalize, d_part, d_norm, st, c.wav_norm_eps));
     }
     if (!lnmode) {
         Prof pr(e, st, "gn_stats", 0, 4.0 * B * n_max);

@@ -86,6 +86,10 @@ struct FbankPlan {
     int size, shift, padded, nbin, nmel;
     float* dft = nullptr;     // (2*nbin, size) fp32: rows 0..nbin-1 cos, nbin.. -sin, pre-processing folded in
     float* banksT = nullptr;  // (nbin, nmel)
+};
+// Scratch is per (device, STREAM): the plan's constants are shared, but two experts / two streams running the same
+// configuration concurrently must not share the spectrum workspace (re-use within one stream is stream-ordered).
+struct FbankScratch {
     float* spec = nullptr;    // workspace (frames, 2*nbin)
     size_t spec_elems = 0;
     float* stage = nullptr;   // aligned copy of a misaligned waveform
@@ -94,6 +98,7 @@ struct FbankPlan {
 
 std::mutex g_mu;
 std::map<std::vector<long>, FbankPlan> g_plans;
+std::map<std::pair<int, uintptr_t>, FbankScratch> g_scratch;
 
 hipError_t build_plan(FbankPlan& pl, int nmel, int size, int shift, double preemph, int sample_rate) {
     pl.size = size;
@@ -178,25 +183,26 @@ hipError_t launch_fbank(const FbankParams& c, const float* wav, long n, float* o
         if (e != hipSuccess) return e;
     }
     const int N2 = 2 * pl.nbin;
-    if ((size_t)T * N2 > pl.spec_elems) {
-        if (pl.spec) (void)hipFree(pl.spec);  // device-synchronising: nothing in flight still uses it
-        pl.spec = nullptr;
-        pl.spec_elems = (size_t)T * N2 + (size_t)T * N2 / 4;
-        e = hipMalloc((void**)&pl.spec, pl.spec_elems * 4);
+    FbankScratch& sc = g_scratch[std::make_pair(dev, (uintptr_t)st)];
+    if ((size_t)T * N2 > sc.spec_elems) {
+        if (sc.spec) (void)hipFree(sc.spec);  // device-synchronising: nothing in flight still uses it
+        sc.spec = nullptr;
+        sc.spec_elems = (size_t)T * N2 + (size_t)T * N2 / 4;
+        e = hipMalloc((void**)&sc.spec, sc.spec_elems * 4);
         if (e != hipSuccess) return e;
     }
     const float* a = wav;
     if (((uintptr_t)wav) & 15) {  // the GEMM loads 16-byte vectors: stage a misaligned waveform once
-        if ((size_t)n > pl.stage_elems) {
-            if (pl.stage) (void)hipFree(pl.stage);
-            pl.stage = nullptr;
-            pl.stage_elems = (size_t)n + (size_t)n / 4;
-            e = hipMalloc((void**)&pl.stage, pl.stage_elems * 4);
+        if ((size_t)n > sc.stage_elems) {
+            if (sc.stage) (void)hipFree(sc.stage);
+            sc.stage = nullptr;
+            sc.stage_elems = (size_t)n + (size_t)n / 4;
+            e = hipMalloc((void**)&sc.stage, sc.stage_elems * 4);
             if (e != hipSuccess) return e;
         }
-        e = hipMemcpyAsync(pl.stage, wav, (size_t)n * 4, hipMemcpyDeviceToDevice, st);
+        e = hipMemcpyAsync(sc.stage, wav, (size_t)n * 4, hipMemcpyDeviceToDevice, st);
         if (e != hipSuccess) return e;
-        a = pl.stage;
+        a = sc.stage;
     }
     GemmParams g{};
     g.A = a;
@@ -207,12 +213,12 @@ hipError_t launch_fbank(const FbankParams& c, const float* wav, long n, float* o
     g.N = N2;
     g.K = size;
     g.batches = 1;
-    g.out32 = pl.spec;
+    g.out32 = sc.spec;
     g.ldo = N2;
     g.o_bs = 0;
     e = launch_gemm(F32, g, st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(fbank_mel_kernel, dim3((unsigned)T), dim3(128), pl.nbin * sizeof(float), st, pl.spec, pl.nbin, N2,
+    hipLaunchKernelGGL(fbank_mel_kernel, dim3((unsigned)T), dim3(128), pl.nbin * sizeof(float), st, sc.spec, pl.nbin, N2,
                        pl.banksT, pl.nmel, 1.1920928955078125e-07f, out, ldo);
     if (c.delta_order > 0) {
         const int nw = (c.delta_win - 1) / 2;

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void wav_sum_kernel(WavTable w, double* partia
     }
 }
 
-__global__ void wav_norm_final_kernel(WavTable w, const double* partial, int chunks, int normalize, float2* norm) {
+__global__ void wav_norm_final_kernel(WavTable w, const double* partial, int chunks, int normalize, double eps, float2* norm) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= w.B) return;
     if (!normalize) {
@@ -74,7 +74,7 @@ __global__ void wav_norm_final_kernel(WavTable w, const double* partial, int chu
     const double mean = s / n;
     double var = s2 / n - mean * mean;  // biased, like F.layer_norm
     var = var > 0 ? var : 0;
-    norm[b] = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)LN_EPS)));
+    norm[b] = make_float2((float)mean, (float)(1.0 / sqrt(var + eps)));
 }
 
 // partial[b][chunk][j][0] = sum_t x[s0 t + j];  [1+jj] = sum_t x[s0 t + j] x[s0 t + jj]
@@ -305,10 +305,10 @@ size_t stats_partial_elems(int B, long n_max) {
     return (size_t)B * (c1 > c2 ? c1 : c2);
 }
 
-hipError_t launch_wav_norm_stats(const WavTable& w, int normalize, double* partial, float2* norm, hipStream_t s) {
+hipError_t launch_wav_norm_stats(const WavTable& w, int normalize, double* partial, float2* norm, hipStream_t s, float eps) {
     const int chunks = (int)((w.n_max + STAT_CHUNK - 1) / STAT_CHUNK);
     if (normalize) hipLaunchKernelGGL(wav_sum_kernel, dim3(chunks, w.B), dim3(256), 0, s, w, partial, chunks);
-    hipLaunchKernelGGL(wav_norm_final_kernel, dim3((w.B + 63) / 64), dim3(64), 0, s, w, partial, chunks, normalize, norm);
+    hipLaunchKernelGGL(wav_norm_final_kernel, dim3((w.B + 63) / 64), dim3(64), 0, s, w, partial, chunks, normalize, (double)(eps > 0.f ? eps : LN_EPS), norm);
     return hipGetLastError();
 }
 

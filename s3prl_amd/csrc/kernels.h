@@ -63,7 +63,8 @@ struct WavTable {
 };
 constexpr int STAT_K0_MAX = 16;  // conv0 kernel width limit for the closed-form GroupNorm statistics
 // per-utterance mean / rstd of the raw waveform (task_cfg.normalize); norm[b] = {mean, rstd}; identity if !normalize
-hipError_t launch_wav_norm_stats(const WavTable& w, int normalize, double* partial, float2* norm, hipStream_t s);
+hipError_t launch_wav_norm_stats(const WavTable& w, int normalize, double* partial, float2* norm, hipStream_t s,
+                                 float eps = 0.f /* 0 = LN_EPS; Hugging Face feature extractors: 1e-7 */);
 // GroupNorm(C,C) statistics of conv0's output from the k0 + k0*(k0+1)/2 lag sums of the waveform, then the
 // fused per-(b,c) affine:  gn[b][c] = {scale, shift} with  y = conv0_raw * scale + shift
 hipError_t launch_gn_stats(const WavTable& w, const float2* norm, const float* w0 /*[C][k0]*/, const float* gamma,

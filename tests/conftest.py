@@ -35,6 +35,18 @@ def load_golden(name):
     meta = json.loads(bytes(z["meta"]).decode())
     cfg = named_config(meta["config"])
     weights = synth_weights(cfg, meta["weight_seed"])
+    if meta.get("hf"):
+        # Hugging Face fixtures: the checkpoint directory is re-written from the seeds (tests/hf_util.py) and read back by
+        # the product reader s3prl_amd.hf (no transformers): its config carries HF's mask rule and normalisation eps
+        import tempfile
+
+        from hf_util import write_hf_dir
+        from s3prl_amd.hf import load_hf_checkpoint
+
+        with tempfile.TemporaryDirectory() as tmp:
+            cfg, back, _ = load_hf_checkpoint(write_hf_dir(tmp, cfg, weights, meta["hf"]))
+        assert set(back) == set(weights) and all(np.array_equal(back[k].reshape(weights[k].shape), weights[k]) for k in weights)
+        weights = back
     wavs = synth_wavs(meta["lengths"], meta["wav_seed"], dc=meta["dc"], scale=meta["scale"])
     hs = [z[f"hs{l}"] for l in range(meta.get("n_states", cfg.encoder_layers + 1))]
     return meta, cfg, weights, wavs, hs, z["norms"]

@@ -254,7 +254,51 @@ def make_feat_case(name: str):
     print(f"{name}: {len(all_hs)} x {tuple(all_hs[0].shape)} -> feat {tuple(hs.shape)}, {os.path.getsize(path) / 1e3:.0f} kB")
 
 
+# Hugging Face checkpoints through the reference's hf_hubert / hf_wav2vec2 experts (upstream/hf_hubert/expert.py:12-41):
+# transformers' HubertModel / Wav2Vec2Model + Wav2Vec2FeatureExtractor on a checkpoint directory written by tests/hf_util.py
+# name -> (config, model_type, weight seed, wav seed, lengths, subsampling, dc, scale)
+HF_CASES = {
+    "hf_tiny_hubert_pad": ("tiny_hubert", "hubert", 21, 51, [4000, 2345, 3111, 800], (1, 1), 0.0, 1.0),
+    "hf_tiny_hubert_large_pad": ("tiny_hubert_large", "hubert", 22, 52, [4000, 2345, 3111], (1, 1), 0.3, 0.05),
+    "hf_tiny_wav2vec2_pad": ("tiny_wav2vec2", "wav2vec2", 23, 53, [3500, 4000, 1700], (1, 1), 0.0, 1.0),
+    "hf_hubert_base_pseudo": ("hubert_base", "hubert", 0, 54, [23456, 16000], (4, 8), 0.0, 1.0),
+    "hf_wav2vec2_large_pseudo": ("wav2vec2_large", "wav2vec2", 0, 55, [16000, 12000], (4, 16), 0.1, 0.02),
+}
+
+
+def make_hf_case(name: str):
+    import torch
+
+    cfg_name, mtype, wseed, xseed, lengths, (ts, cs), dc, scale = HF_CASES[name]
+    cfg = named_config(cfg_name)
+    weights = synth_weights(cfg, wseed)
+    wavs = synth_wavs(lengths, xseed, dc=dc, scale=scale)
+    _import_reference()
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from hf_util import write_hf_dir
+
+    if mtype == "hubert":
+        from s3prl.upstream.hf_hubert.expert import UpstreamExpert
+    else:
+        from s3prl.upstream.hf_wav2vec2.expert import UpstreamExpert
+    with tempfile.TemporaryDirectory() as tmp:
+        write_hf_dir(tmp, cfg, weights, mtype)
+        expert = UpstreamExpert(tmp).eval()
+        with torch.no_grad():
+            hs = [h.numpy() for h in expert([torch.from_numpy(w.copy()) for w in wavs])["hidden_states"]]
+    assert len(hs) == cfg.encoder_layers + 1
+    meta = dict(config=cfg_name, hf=mtype, weight_seed=wseed, wav_seed=xseed, lengths=lengths, t_stride=ts, c_stride=cs, dc=dc,
+                scale=scale, shape=list(hs[0].shape), n_states=len(hs),
+                reference="s3prl 0.4.18 @ /root/reference upstream/hf_%s on transformers %s, torch CPU fp32" % (mtype, __import__("transformers").__version__))
+    arrays = {f"hs{l}": np.ascontiguousarray(h[:, ::ts, ::cs]) for l, h in enumerate(hs)}
+    arrays["norms"] = np.array([np.linalg.norm(h.astype(np.float64)) for h in hs])
+    arrays["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    path = os.path.join(HERE, f"{name}.npz")
+    np.savez_compressed(path, **arrays)
+    print(f"{name}: {len(hs)} x {hs[0].shape} -> {os.path.getsize(path) / 1e3:.0f} kB")
+
+
 if __name__ == "__main__":
-    names = sys.argv[1:] or (list(CASES) + list(FEAT_CASES))
+    names = sys.argv[1:] or (list(CASES) + list(FEAT_CASES) + list(HF_CASES))
     for n in names:
-        make_feat_case(n) if n in FEAT_CASES else make_case(n)
+        make_feat_case(n) if n in FEAT_CASES else (make_hf_case(n) if n in HF_CASES else make_case(n))
