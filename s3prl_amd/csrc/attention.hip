@@ -22,6 +22,7 @@ constexpr int HD = 64;        // head dim
 constexpr int QT = 128;       // queries per workgroup (4 waves x 32)
 constexpr int KT = 32;        // keys per tile
 constexpr int KS32 = HD + 4;  // fp32 LDS row stride (floats): 272 B rows -> conflict-free ds_read_b128
+constexpr int BIAS_PAD = 64;  // WavLM bias window: entries past T + QT - 1 so that the keys of a partial last tile stay in range
 
 __device__ __forceinline__ int crow(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnParams p) {
         const int R = p.table_R;
         const float* src = p.bias_table + (long)head * (2 * R + 1) + R;
         const int rel0 = -((int)blockIdx.x * QT + QT - 1);  // smallest key - query this workgroup can meet
-        for (int i = threadIdx.x; i < p.T + QT - 1; i += 256) bias_s[i] = src[min(max(rel0 + i, -R), R)];
+        for (int i = threadIdx.x; i < p.T + QT - 1 + BIAS_PAD; i += 256) bias_s[i] = src[min(max(rel0 + i, -R), R)];
         btab = bias_s;  // made visible by the first __syncthreads() of the key loop
     }
     const float gate = (btab && p.gate) ? p.gate[((long)b * p.H + head) * p.T + q_c] : 1.f;
@@ -120,10 +121,13 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnParams p) {
         // query's tile max exceeds it by more than 8 — softmax is invariant to the reference point (exact in real
         // arithmetic, rounding-level in fp32) and the 32 O registers are then almost never rescaled
         if (btab) {
+            // branch-free: the window is padded by BIAS_PAD entries, so keys of the last (partial) tile index valid LDS;
+            // their scores are masked below.  16 reads at compile-time offsets from one base instead of 16 predicated
+            // read-wait-add sequences
+            {
+                const float* bb = btab + (kt * KT + 4 * half - q_c + bias_off);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kt * KT + crow(r, half);
-                if (key < p.T) s[r] += gate * btab[key - q_c + bias_off];
+                for (int r = 0; r < 16; ++r) s[r] = fmaf(gate, bb[(r & 3) + 8 * (r >> 2)], s[r]);
             }
         }
         if (kt * KT + KT > valid) {
@@ -196,8 +200,11 @@ template <> struct Mma16<f16_tag> {
     }
 };
 
-template <typename T>
-__global__ __launch_bounds__(256, 4) void attn_h16_kernel(AttnParams p) {
+// BIAS: the WavLM relative-position bias path compiled in (134 registers: 3 waves per SIMD; capped at 128 its 16 table
+// reads in flight spill to scratch).  The bias-free variant fits 115 registers = 4 waves per SIMD; 3 vs 4 waves is a
+// wash on HuBERT shapes (A/B with the `attn_lds_pad` tuning knob: 0.61 vs 0.61 ms per HuBERT-base forward).
+template <typename T, bool BIAS>
+__global__ __launch_bounds__(256, 3) void attn_h16_kernel(AttnParams p) {
     __shared__ __attribute__((aligned(16))) u16 Ks[2 * KBUF16];
     __shared__ __attribute__((aligned(16))) u16 Vt[2 * VBUF16];
     const int b = blockIdx.z, head = blockIdx.y;
@@ -220,11 +227,11 @@ __global__ __launch_bounds__(256, 4) void attn_h16_kernel(AttnParams p) {
     // global gather would bound the kernel
     extern __shared__ float bias_s[];
     const float* btab = nullptr;
-    if (p.bias_table) {
+    if (BIAS && p.bias_table) {
         const int R = p.table_R;
         const float* src = p.bias_table + (long)head * (2 * R + 1) + R;
         const int rel0 = -((int)blockIdx.x * QT + QT - 1);  // smallest key - query this workgroup can meet
-        for (int i = threadIdx.x; i < p.T + QT - 1; i += 256) bias_s[i] = src[min(max(rel0 + i, -R), R)];
+        for (int i = threadIdx.x; i < p.T + QT - 1 + BIAS_PAD; i += 256) bias_s[i] = src[min(max(rel0 + i, -R), R)];
         btab = bias_s;  // made visible by the first __syncthreads() of the key loop
     }
     const float gate = (btab && p.gate) ? p.gate[((long)b * p.H + head) * p.T + q_c] : 1.f;
@@ -290,11 +297,11 @@ __global__ __launch_bounds__(256, 4) void attn_h16_kernel(AttnParams p) {
                 const uint4 kf = *(const uint4*)(ks + (h * 32 + l31) * KS16 + st * 16 + 8 * half);
                 sc = Mma16<T>::run(kf, qf[st], sc);
             }
-            if (btab) {
+            if (BIAS && btab) {
+                {
+                    const float* bb = btab + (k0 + 4 * half - q_c + bias_off);  // branch-free, see attn_f32_kernel
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = k0 + crow(r, half);
-                    if (key < p.T) sc[r] += gate * btab[key - q_c + bias_off];
+                    for (int r = 0; r < 16; ++r) sc[r] = fmaf(gate, bb[(r & 3) + 8 * (r >> 2)], sc[r]);
                 }
             }
             if (k0 + 32 > valid) {
@@ -392,7 +399,7 @@ __global__ __launch_bounds__(256, 3) void attn_x3_kernel(AttnParams p) {
         const int R = p.table_R;
         const float* src = p.bias_table + (long)head * (2 * R + 1) + R;
         const int rel0 = -((int)blockIdx.x * QT + QT - 1);  // smallest key - query this workgroup can meet
-        for (int i = threadIdx.x; i < p.T + QT - 1; i += 256) bias_s[i] = src[min(max(rel0 + i, -R), R)];
+        for (int i = threadIdx.x; i < p.T + QT - 1 + BIAS_PAD; i += 256) bias_s[i] = src[min(max(rel0 + i, -R), R)];
         btab = bias_s;  // made visible by the first __syncthreads()
     }
     const float gate = (btab && p.gate) ? p.gate[((long)b * p.H + head) * p.T + q_c] : 1.f;
@@ -467,10 +474,10 @@ __global__ __launch_bounds__(256, 3) void attn_x3_kernel(AttnParams p) {
                 sc = Mma16<bf16_tag>::run(kh, qh[st], sc);
             }
             if (btab) {
+                {
+                    const float* bb = btab + (k0 + 4 * half - q_c + bias_off);  // branch-free, see attn_f32_kernel
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = k0 + crow(r, half);
-                    if (key < p.T) sc[r] += gate * btab[key - q_c + bias_off];
+                    for (int r = 0; r < 16; ++r) sc[r] = fmaf(gate, bb[(r & 3) + 8 * (r >> 2)], sc[r]);
                 }
             }
             if (k0 + 32 > valid) {
@@ -578,15 +585,23 @@ __global__ __launch_bounds__(256) void wavlm_gate_kernel(const float* x, const f
 
 }  // namespace
 
+int g_attn_lds_pad = 0;  // tuning: extra dynamic LDS per workgroup of the 16-bit kernel (caps the workgroups per CU)
+
 hipError_t launch_attention(int dtype, const AttnParams& p, hipStream_t s) {
     if (p.B <= 0 || p.T <= 0) return hipSuccess;
     dim3 grid((p.T + QT - 1) / QT, p.H, p.B), block(256);
-    const size_t dyn = p.bias_table ? (size_t)(p.T + QT - 1) * sizeof(float) : 0;  // the workgroup's table window
+    const size_t dyn = p.bias_table ? (size_t)(p.T + QT - 1 + BIAS_PAD) * sizeof(float) : 0;  // the workgroup's table window
     if (dyn > 24 * 1024) return hipErrorInvalidValue;  // T <= 6017 frames (120 s): the window must fit beside K/V (engine checks)
     switch (dtype) {
         case F32: hipLaunchKernelGGL(attn_f32_kernel, grid, block, dyn, s, p); break;
-        case BF16: hipLaunchKernelGGL(attn_h16_kernel<bf16_tag>, grid, block, dyn, s, p); break;
-        case F16: hipLaunchKernelGGL(attn_h16_kernel<f16_tag>, grid, block, dyn, s, p); break;
+        case BF16:
+            if (p.bias_table) hipLaunchKernelGGL((attn_h16_kernel<bf16_tag, true>), grid, block, dyn, s, p);
+            else hipLaunchKernelGGL((attn_h16_kernel<bf16_tag, false>), grid, block, dyn + g_attn_lds_pad, s, p);
+            break;
+        case F16:
+            if (p.bias_table) hipLaunchKernelGGL((attn_h16_kernel<f16_tag, true>), grid, block, dyn, s, p);
+            else hipLaunchKernelGGL((attn_h16_kernel<f16_tag, false>), grid, block, dyn + g_attn_lds_pad, s, p);
+            break;
         case 3: {  // S3ENC_F32X3: fp32 q|k|v and output, split-precision products; all of its LDS is dynamic
             const size_t lds = (size_t)(4 * KBUF16 + 4 * VBUF16) * sizeof(u16) + dyn;
             hipError_t e = ensure_dynamic_lds<attn_x3_kernel>((int)lds);

@@ -1409,6 +1409,11 @@ int s3enc_set_tuning(const char* key, int32_t value) {
         g_gemm16_big = value;
         return 0;
     }
+    if (!strcmp(key, "attn_lds_pad")) {
+        if (value < 0 || value > 48 * 1024) return fail("attn_lds_pad must be 0..49152");
+        g_attn_lds_pad = value;
+        return 0;
+    }
     if (!strcmp(key, "x3_pack_cache")) {
         g_x3_pack_cache = value != 0;
         return 0;

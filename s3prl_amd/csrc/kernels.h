@@ -112,6 +112,7 @@ struct AttnParams {
     int table_R = 0;
     const float* gate;        // WavLM: [B][H][T] or null (then gate = 1)
 };
+extern int g_attn_lds_pad;
 hipError_t launch_attention(int dtype, const AttnParams& p, hipStream_t s);
 // WavLM gate (wavlm/modules.py:535-549) from the layer input x (fp32 rows of D): gate[b][h][t]
 hipError_t launch_wavlm_gate(const float* x, const float* grep_w /*[8][64]*/, const float* grep_b /*[8]*/,
