@@ -26,6 +26,21 @@ constexpr int BIAS_PAD = 64;  // WavLM bias window: entries past T + QT - 1 so t
 
 __device__ __forceinline__ int crow(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
+// Exchange between the two half-waves (lane l <-> l ^ 32) WITHOUT the LDS: v_permlane32_swap swaps the upper half of one
+// register with the lower half of another, so swap(x, copy of x) leaves {x_lo, x_lo} and {x_hi, x_hi}.  __shfl_xor(.., 32)
+// lowers to ds_bpermute_b32 + s_waitcnt lgkmcnt(0), i.e. an LDS round trip that also drains the prefetched K / V fragment
+// reads — once per 32-key half on the softmax's critical path.
+__device__ __forceinline__ float xhalf_max(float x) {
+    const unsigned u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xhalf_sum(float x) {
+    const unsigned u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 struct BiasCtx {
     const float* table;  // this head's [2T-1] row or null
     float gate;
@@ -137,7 +152,7 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnParams p) {
         float mx = s[0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = xhalf_max(mx);
         if (__any(mx > m_run + 8.f)) {
             const float m_new = fmaxf(m_run, mx);
             const float alpha = __expf(m_run - m_new);
@@ -167,7 +182,7 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnParams p) {
     }
 #undef A32_LOAD
 #undef A32_STORE
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float l_tot = xhalf_sum(l_run);
     const float inv = 1.f / l_tot;
     if (q_g < p.T) {
         float* op = (float*)p.out + ((long)b * p.T + q_g) * D + head * HD + 4 * half;
@@ -311,7 +326,7 @@ __global__ __launch_bounds__(256, 3) void attn_h16_kernel(AttnParams p) {
             float mx = sc[0];
 #pragma unroll
             for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sc[r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx = xhalf_max(mx);
             if (__any(mx > m_run + 8.f)) {
                 const float m_new = fmaxf(m_run, mx);
                 const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * 1.44269504088896340736f);
@@ -352,7 +367,7 @@ __global__ __launch_bounds__(256, 3) void attn_h16_kernel(AttnParams p) {
     }
 #undef A16_LOAD
 #undef A16_STORE
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float l_tot = xhalf_sum(l_run);
     const float inv = 1.f / l_tot;
     if (q_g < p.T) {
         u16* op = (u16*)p.out + ((long)b * p.T + q_g) * D + head * HD + 4 * half;
@@ -487,7 +502,7 @@ __global__ __launch_bounds__(256, 3) void attn_x3_kernel(AttnParams p) {
             float mx = sc[0];
 #pragma unroll
             for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sc[r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx = xhalf_max(mx);
             if (__any(mx > m_run + 8.f)) {
                 const float m_new = fmaxf(m_run, mx);
                 const float alpha = __expf(m_run - m_new);
@@ -532,7 +547,7 @@ __global__ __launch_bounds__(256, 3) void attn_x3_kernel(AttnParams p) {
     }
 #undef AX3_LOAD
 #undef AX3_STORE
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float l_tot = xhalf_sum(l_run);
     const float inv = 1.f / l_tot;
     if (q_g < p.T) {
         float* op = (float*)p.out + ((long)b * p.T + q_g) * D + head * HD + 4 * half;
