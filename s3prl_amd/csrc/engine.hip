@@ -1046,14 +1046,37 @@ int forward_impl(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
             float* h0 = sink.slot32(si0) ? sink.slot32(si0) : other(pc_out);
             void* h16 = dt == F32 ? nullptr : (sink.slot16(si0) ? sink.slot16(si0) : xT);
             Prof pr(e, st, "layernorm:enc", 0, (double)M * D * (8 + (dt == F32 ? 0 : es)));
+            LnGate g0;  // post-LN WavLM: the gate of layer 0 reads this LayerNorm's output
+            if (gated) {
+                g0.gw = (const float*)e->layers[0].grep_w.p;
+                g0.gb = (const float*)e->layers[0].grep_b.p;
+                g0.ga = (const float*)e->layers[0].grep_a.p;
+                g0.gate = (float*)gate;
+                g0.T = (int)T;
+                g0.H = H;
+            }
             HIP_TRY(launch_layernorm(dt, pc_out, (const float*)e->eln_g.p, (const float*)e->eln_b.p, M, D, 0, h0, h16, st,
-                                     sink.acc(si0, 2)));
+                                     sink.acc(si0, 2), g0));
             x_cur = h0;
             a16_cur = h16;
             HIP_TRY(sink.done(si0));
         }
     }
     const float* d_table = c.rel_pos ? (const float*)e->rel_table.p : nullptr;
+    // WavLM gate of layer l's attention, computed by the LayerNorm that produces that attention's input
+    auto gate_of = [&](int l) {
+        LnGate g;
+        if (gated && l < NL) {
+            const LayerW& w = e->layers[l];
+            g.gw = (const float*)w.grep_w.p;
+            g.gb = (const float*)w.grep_b.p;
+            g.ga = (const float*)w.grep_a.p;
+            g.gate = (float*)gate;
+            g.T = (int)T;
+            g.H = H;
+        }
+        return g;
+    };
 
     const double gM = (double)M;
     int si_cur = si_hidden(0);  // state index of x_cur (pre-LN featurize: its term is added by the LayerNorm that reads it)
@@ -1064,20 +1087,17 @@ int forward_impl(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
         const float* gate_src;  // WavLM: the attention module's input
         if (prel) {
             Prof pr(e, st, "layernorm:ln1", 0, gM * D * (4 + es));
+            // WavLM: the gate reads LN1's output — computed inside this pass (no fp32 copy, no separate kernel)
             HIP_TRY(launch_layernorm(dt, x_cur, (const float*)Lw.ln1g.p, (const float*)Lw.ln1b.p, M, D, 0,
-                                     dt == F32 ? (float*)xT : (gated ? (float*)tmp2 : nullptr), dt == F32 ? nullptr : xT, st,
-                                     sink.acc(si_cur, 1)));
+                                     dt == F32 ? (float*)xT : nullptr, dt == F32 ? nullptr : xT, st, sink.acc(si_cur, 1),
+                                     gate_of(l)));
             a_in = xT;
-            gate_src = dt == F32 ? (const float*)xT : (const float*)tmp2;
+            gate_src = nullptr;
         } else {
             a_in = dt == F32 ? (const void*)x_cur : (const void*)a16_cur;
             gate_src = x_cur;
         }
-        if (gated) {
-            Prof pr(e, st, "wavlm_gate", 2.0 * M * H * 64 * 8, gM * D * 4);
-            HIP_TRY(launch_wavlm_gate(gate_src, (const float*)Lw.grep_w.p, (const float*)Lw.grep_b.p, (const float*)Lw.grep_a.p,
-                                      B, (int)T, H, (float*)gate, st));
-        }
+        (void)gate_src;  // the gate of this layer was written by the LayerNorm that produced its attention input
         {
             GemmParams g{};
             g.A = a_in;
@@ -1204,7 +1224,7 @@ int forward_impl(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
             void* h16 = dt == F32 ? nullptr : (sink.slot16(si_next) ? sink.slot16(si_next) : xT);
             Prof pr(e, st, "layernorm:ln2", 0, gM * D * (8 + (dt == F32 ? 0 : es)));
             HIP_TRY(launch_layernorm(dt, (const float*)tmp1, (const float*)Lw.ln2g.p, (const float*)Lw.ln2b.p, M, D, 0, x_next,
-                                     h16, st, sink.acc(si_next, 2)));
+                                     h16, st, sink.acc(si_next, 2), gate_of(l + 1)));
             a16_cur = h16;
         }
         HIP_TRY(sink.done(si_next));

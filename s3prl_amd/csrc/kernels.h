@@ -95,9 +95,19 @@ struct LnAcc {
     int norm = 0;
     int init = 0;  // first term: write instead of add
 };
+// WavLM gate (wavlm/modules.py:535-549) of the attention module that will read this LayerNorm's OUTPUT, fused into the
+// LayerNorm pass (the row is in registers): gate[b][h][t] for the (b, t) row; needs C == H * 64.  Replaces a separate
+// pass over the (B*T, D) fp32 tensor (and, in the 16-bit modes, the fp32 copy written only for it).
+struct LnGate {
+    const float* gw = nullptr;  // grep_linear.weight (8, 64)
+    const float* gb = nullptr;  // grep_linear.bias (8)
+    const float* ga = nullptr;  // grep_a (H)
+    float* gate = nullptr;      // (B, H, T) or null: no gate
+    int T = 0, H = 0;
+};
 // act: 0 none, 1 erf-GELU of the mode (fp32: libm erff; 16-bit: the 1.5e-7 erf), 2 the 1.5e-7 erf regardless of dtype
 hipError_t launch_layernorm(int dtype, const float* x, const float* gamma, const float* beta, long rows, int C, int act,
-                            float* out32, void* out16, hipStream_t s, const LnAcc& fa = LnAcc());
+                            float* out32, void* out16, hipStream_t s, const LnAcc& fa = LnAcc(), const LnGate& gt = LnGate());
 // a state produced by a non-LayerNorm kernel: its 16-bit copy (out16, dtype BF16 / F16) and / or its Featurizer term
 hipError_t launch_emit_state(int dtype, const float* x, long rows, int C, void* out16, const LnAcc& fa, hipStream_t s);
 hipError_t launch_add(const float* a, const float* b, float* out, long n, hipStream_t s);  // out = a + b, n % 4 == 0

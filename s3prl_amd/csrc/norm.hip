@@ -15,7 +15,7 @@ namespace {
 template <typename T, int NCH>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, long rows, int C, int act,
-                                                        float* out32, void* out16, LnAcc fa) {
+                                                        float* out32, void* out16, LnAcc fa, LnGate gt) {
     typedef typename Cvt<T>::store_t store_t;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -57,10 +57,42 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
             *dst = t;
         }
     }
+    // WavLM gate of the OUTPUT row: this lane's 4 dims of its head (chunk ch covers dims 4ch..4ch+3 of head ch >> 4)
+    float gwa[4] = {0.f, 0.f, 0.f, 0.f}, gwb[4] = {0.f, 0.f, 0.f, 0.f}, gba = 0.f, gbb = 0.f;
+    if (gt.gate) {
+        const int k4 = (lane & 15) * 4;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            gwa[u] = (gt.gw[0 * 64 + k4 + u] + gt.gw[1 * 64 + k4 + u]) + (gt.gw[2 * 64 + k4 + u] + gt.gw[3 * 64 + k4 + u]);
+            gwb[u] = (gt.gw[4 * 64 + k4 + u] + gt.gw[5 * 64 + k4 + u]) + (gt.gw[6 * 64 + k4 + u] + gt.gw[7 * 64 + k4 + u]);
+        }
+        gba = (gt.gb[0] + gt.gb[1]) + (gt.gb[2] + gt.gb[3]);
+        gbb = (gt.gb[4] + gt.gb[5]) + (gt.gb[6] + gt.gb[7]);
+    }
     float ys = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int ch = lane + 64 * i;
+        if (gt.gate) {  // wave-uniform; every lane takes part in the row reduction, lanes past the row contribute 0
+            float sa = 0.f, sb = 0.f;
+            if (ch < nch) {
+                const float4 g = *(const float4*)(gamma + 4 * ch);
+                const float4 bt = *(const float4*)(beta + 4 * ch);
+                const float y0 = (v[i].x - mu) * rs * g.x + bt.x, y1 = (v[i].y - mu) * rs * g.y + bt.y;
+                const float y2 = (v[i].z - mu) * rs * g.z + bt.z, y3 = (v[i].w - mu) * rs * g.w + bt.w;
+                sa = y0 * gwa[0] + y1 * gwa[1] + y2 * gwa[2] + y3 * gwa[3];
+                sb = y0 * gwb[0] + y1 * gwb[1] + y2 * gwb[2] + y3 * gwb[3];
+            }
+            sa = row16_sum(sa);
+            sb = row16_sum(sb);
+            const int h = ch >> 4;
+            if (ch < nch && (lane & 15) == 0 && h < gt.H) {
+                const float a = 1.f / (1.f + __expf(-(sa + gba)));
+                const float bb = 1.f / (1.f + __expf(-(sb + gbb)));
+                const long b_ = row / gt.T, t_ = row - b_ * gt.T;
+                gt.gate[(b_ * gt.H + h) * gt.T + t_] = a * (bb * gt.ga[h] - 1.f) + 2.f;
+            }
+        }
         if (ch >= nch) continue;
         const float4 g = *(const float4*)(gamma + 4 * ch);
         const float4 bt = *(const float4*)(beta + 4 * ch);
@@ -196,10 +228,10 @@ __global__ __launch_bounds__(256) void add_kernel(const float4* a, const float4*
 
 template <typename T>
 hipError_t ln_dispatch(const float* x, const float* gamma, const float* beta, long rows, int C, int act, float* out32,
-                       void* out16, const LnAcc& fa, hipStream_t s) {
+                       void* out16, const LnAcc& fa, const LnGate& gt, hipStream_t s) {
     const int per_lane = ((C >> 2) + 63) / 64;
     dim3 grid((unsigned)((rows + 3) / 4)), block(256);
-#define S3_LN(N) hipLaunchKernelGGL((layernorm_kernel<T, N>), grid, block, 0, s, x, gamma, beta, rows, C, act, out32, out16, fa)
+#define S3_LN(N) hipLaunchKernelGGL((layernorm_kernel<T, N>), grid, block, 0, s, x, gamma, beta, rows, C, act, out32, out16, fa, gt)
     if (per_lane <= 1) S3_LN(1);
     else if (per_lane == 2) S3_LN(2);
     else if (per_lane == 3) S3_LN(3);
@@ -212,13 +244,14 @@ hipError_t ln_dispatch(const float* x, const float* gamma, const float* beta, lo
 }  // namespace
 
 hipError_t launch_layernorm(int dtype, const float* x, const float* gamma, const float* beta, long rows, int C, int act,
-                            float* out32, void* out16, hipStream_t s, const LnAcc& fa) {
+                            float* out32, void* out16, hipStream_t s, const LnAcc& fa, const LnGate& gt) {
     if (rows <= 0) return hipSuccess;
     if ((C & 3) || C > 2048) return hipErrorInvalidValue;
+    if (gt.gate && (gt.H * 64 != C || gt.T <= 0 || act)) return hipErrorInvalidValue;
     switch (dtype) {
-        case F32: return ln_dispatch<float>(x, gamma, beta, rows, C, act, out32, out16, fa, s);
-        case BF16: return ln_dispatch<bf16_tag>(x, gamma, beta, rows, C, act, out32, out16, fa, s);
-        case F16: return ln_dispatch<f16_tag>(x, gamma, beta, rows, C, act, out32, out16, fa, s);
+        case F32: return ln_dispatch<float>(x, gamma, beta, rows, C, act, out32, out16, fa, gt, s);
+        case BF16: return ln_dispatch<bf16_tag>(x, gamma, beta, rows, C, act, out32, out16, fa, gt, s);
+        case F16: return ln_dispatch<f16_tag>(x, gamma, beta, rows, C, act, out32, out16, fa, gt, s);
     }
     return hipErrorInvalidValue;
 }
