@@ -192,13 +192,11 @@ __global__ __launch_bounds__(256) void conv0_kernel(Conv0Params p) {
     __syncthreads();
 
     const float invC = 1.f / (float)p.C;
-    for (int f = wave / CS; f < C0_FT; f += 4 / CS) {
-        const long t = t0 + f;
-        if (t >= p.L0) break;
+    // one output frame: conv taps -> {GroupNorm affine | LayerNorm over C} -> GELU, into v[g][0..3] (this lane's channels)
+    auto frame = [&](int f, float (&v)[NG][4]) {
         float xv[K0];
 #pragma unroll
         for (int j = 0; j < K0; ++j) xv[j] = xs[f * p.s0 + j];
-        float v[NG][4];
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             if constexpr (FAST) {  // same per-channel tap order, two channels per instruction
@@ -254,6 +252,16 @@ __global__ __launch_bounds__(256) void conv0_kernel(Conv0Params p) {
                 gelu4<FAST>(v[g][0], v[g][1], v[g][2], v[g][3]);
             }
         }
+    };
+    constexpr int FSTEP = 4 / CS;  // frames between two iterations of one wave
+    // (tried for the 16-bit GroupNorm variant and dropped: two frames per iteration with a DPP quad exchange so that every
+    //  lane issues ONE 16-byte store per two frames instead of two 8-byte ones — same 0.42-0.48 ms: the kernel is bound by
+    //  the two transcendentals of each GELU, not by store issue; packed fp32 taps did not move it either)
+    for (int f = wave / CS; f < C0_FT; f += FSTEP) {
+        const long t = t0 + f;
+        if (t >= p.L0) break;
+        float v[NG][4];
+        frame(f, v);
         store_t* o = (store_t*)p.out + ((long)b * p.L0 + t) * p.C;
         if constexpr (WIDE) {
             if (act[0])  // C % 8 == 0 on this path (launcher): both groups are in or out together
