@@ -27,6 +27,15 @@ SHAPES = {  # name: (batches, M, N, K, lda, a_bs_rows)
     "L_fc2": (1, 15968, 1024, 4096, 4096, None),
 }
 
+FILL = "randn"
+
+
+def _fill(n, scale=1.0):
+    """operand data: "randn" (what the path sees) or "zeros" (the DVFS probe: MI355X_MICROARCH.md 'DVFS give-back' — a
+    power-limited kernel runs faster on zero-filled operands at identical instruction counts)"""
+    return torch.zeros(n, device="cuda") if FILL == "zeros" else torch.randn(n, device="cuda") * scale
+
+
 def run(dtype, variants=None, rounds=5, shapes=None, reps=10):
     x3 = dtype == "fp32x3"  # variants: gemm_x3_mode 0 / 1
     big = dtype not in ("fp32", "fp32x3")
@@ -42,10 +51,10 @@ def run(dtype, variants=None, rounds=5, shapes=None, reps=10):
         if shapes and name not in shapes:
             continue
         if rows is None:
-            A = torch.randn(M * lda, device="cuda").to(td); a_bs = M * lda
+            A = _fill(M * lda).to(td); a_bs = M * lda
         else:
-            A = torch.randn(nb * rows * 512, device="cuda").to(td); a_bs = rows * 512
-        W = (torch.randn(N, K, device="cuda") / K ** 0.5).to(td)
+            A = _fill(nb * rows * 512).to(td); a_bs = rows * 512
+        W = _fill(N * K, 1.0 / K ** 0.5).reshape(N, K).to(td)
         bias = torch.randn(N, device="cuda")
         # epilogue as in the encoder: conv / fc1 -> GELU, operand-type output; qkv -> plain; out_proj / fc2 -> fp32 residual
         # added, fp32 output (the residual stream)
@@ -89,8 +98,10 @@ if __name__ == "__main__":
     ap.add_argument("--variants", default="")
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--fill", default="randn", choices=["randn", "zeros"], help="operand data (zeros: power / DVFS probe)")
     ap.add_argument("--probe", type=int, default=0, help="gemm_variant bits for timing probes (8: every tile loads tile 0)")
     a = ap.parse_args()
+    FILL = a.fill
     if a.probe:
         _lib.check(lib.s3enc_set_tuning(b"gemm_variant", a.probe | 1))
         globals()["CHECK"] = False
