@@ -8,11 +8,13 @@
 // sub-tile (WTM = 128: 8 accumulator tiles of 32x32 = 128 VGPRs; 128 FLOP per staged byte, 0.75 KiB LDS per MFMA).
 //   * staging: LDS-DMA only (global_load_lds_dwordx4, 1 KiB per wave instruction, whole lines of a row per 8 / 4
 //     lanes), issued from INLINE ASM with hand-counted vmcnt: through the builtin hipcc drains the DMA (vmcnt(0))
-//     before the first fragment read of every K-step, which serialises load and compute.  Two configurations ship:
-//       mode 1  256x256 tile, 2 stages of 64 k, one workgroup per CU (128 FLOP per staged byte) — K >= 1024;
+//     before the first fragment read of every K-step, which serialises load and compute.  Configurations:
+//       mode 1  256x256 (or 192x256, whichever leaves fewer idle CU-rounds) tile, 2 stages of 64 k, one workgroup per CU
+//               (128 FLOP per staged byte) — the default for every shape since the 16-bit epilogues store 16 bytes per
+//               lane (round 2: q|k|v 64 vs 72 us, fc1 99 vs 104 us against mode 4);
 //       mode 4  128x256 tile, ring of 3 stages of 32 k with two K-steps in flight, two workgroups per CU that hide
-//               each other's barriers and epilogues — short K (768), where prologue + epilogue are 25-45 % of
-//               a tile's time.
+//               each other's barriers and epilogues — kept as a tuning option (`gemm16_big` = 4);
+//       modes 7-9: the phase-pipelined kernel of gemm16p.hip.
 //     The DMA pieces are interleaved with the MFMA steps (an LDS-DMA instruction costs 60-180 issue cycles).  LDS rows
 //     are XOR-swizzled through the per-lane SOURCE address (the DMA image is lane-linear) so every ds_read_b128
 //     fragment read is bank-conflict free — same layout as gemm.hip.
@@ -24,7 +26,8 @@
 //     degree-5 Horner, 19 VALU) instead of libm's erff (38 VALU with a divergent branch): at K = 768 the erff
 //     epilogue costs about as many VALU cycles as the whole K loop costs MFMA cycles.  The error is 3 orders below
 //     the operand rounding of these modes; the fp32 mode (gemm.hip) keeps erff.
-// Measured: profiles/r01_gemm16_variants.md (550-1100 TF on the shapes of the path, 1148 TF at 8192^3).
+// Measured: profiles/r02_gemm16_variants.md, r02_pmc_gemm16.md (700-1000 TF on the shapes of the path, 1.15 PF at 8192^3:
+// MFMA-busy 0.61 at a power-limited ~1.55 GHz; 18 % more on zero-filled operands).
 // Requirements (checked by the launcher, which otherwise falls back to gemm.hip): K a multiple of 64, N / ldo /
 // o_bs multiples of 4, 16-byte aligned operands and outputs.
 #include <type_traits>
