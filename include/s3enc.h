@@ -24,15 +24,21 @@
 extern "C" {
 #endif
 
-#define S3ENC_VERSION 2
+#define S3ENC_VERSION 3
 #define S3ENC_MAX_CONV 16
+#define S3ENC_MAX_RES 4 /* resolutions of a multires-HuBERT U-net: up to 3 rate pairs, 7 encoder blocks */
 
 typedef struct s3enc_encoder* s3enc_handle;
 
 enum { S3ENC_HUBERT = 0, S3ENC_WAV2VEC2 = 1, S3ENC_WAVLM = 2,
        /* DistilHuBERT (upstream/distiller/model.py:83-268): HuBERT-style encoder without the LayerNorm before
         * post_extract_proj, wav2vec2's conv-length frame mask, prediction heads on the last layer */
-       S3ENC_DISTILLER = 3 };
+       S3ENC_DISTILLER = 3,
+       /* multi-resolution HuBERT (upstream/multires_hubert/hubert_model.py:337-852): a U-net of TransformerEncoders
+        * (encoders[i] -> conv adapter -> ... middle_encoder ... -> conv adapter -> decoders[i] + skip) over the frame rates
+        * of mr_ratios; HuBERT's frame mask; the states are every block's layer inputs and output, repeated to the
+        * finest rate and cut to their common length (multires_hubert/expert.py:26-27,49-101) */
+       S3ENC_MULTIRES = 4 };
 /* arithmetic type of the GEMM / attention operands; accumulation, norms, softmax, GELU and the residual
  * stream are always fp32 (the reference's Fp32GroupNorm / Fp32LayerNorm / fp32 softmax guards,
  * wav2vec2_model.py:1826-1853,1899-1900). */
@@ -75,6 +81,12 @@ typedef struct s3enc_config {
                                             * Hugging Face's Wav2Vec2FeatureExtractor uses 1e-7 (upstream/hf_hubert/expert.py:30-37) */
     int32_t pred_heads;                    /* DistilHuBERT: N prediction heads Linear(D, N*D) -> GELU -> SplitLinear(D, N, D)
                                             * (distiller/model.py:155-161, module.py:55-90); 0 otherwise */
+    /* S3ENC_MULTIRES only (MultiresHubertConfig, multires_hubert/hubert_model.py:97-148); encoder_layers = sum(mr_layers) */
+    int32_t mr_pairs;                               /* rate pairs = resolutions - 1 (label_rate_ratios has 2 * mr_pairs entries) */
+    int32_t mr_ratios[2 * (S3ENC_MAX_RES - 1)];     /* label_rate_ratios: up_0, down_0, up_1, down_1, ... */
+    int32_t mr_layers[2 * S3ENC_MAX_RES - 1];       /* layers per block in execution order: encoders..., middle, decoders... */
+    int32_t mr_kernel;                              /* conv_adapator_kernal (7): odd, every rate divides mr_kernel - 1 */
+    int32_t mr_plain;                               /* use_plain_updownsample: ConvDownsampler / ConvUpsampler, else ConvAdapter */
 } s3enc_config;
 
 /* A named fp32 host tensor of the checkpoint, named exactly like the reference state_dict entry
@@ -100,6 +112,9 @@ int s3enc_destroy(s3enc_handle h);
 /* T = frames produced for an n-sample input: floor((L-k)/s)+1 through the conv stack
  * (wav2vec2_model.py:2610-2624).  get_downsample_rates() is the product of the strides (320). */
 int s3enc_num_frames(s3enc_handle h, int64_t n_samples, int32_t* T);
+/* T of the states the forward writes for a batch padded to n_samples: s3enc_num_frames, except for S3ENC_MULTIRES
+ * where every state is cut to the common length of the upsampled blocks (multires_hubert/expert.py:93-101). */
+int s3enc_num_output_frames(s3enc_handle h, int64_t n_samples, int32_t* T);
 int s3enc_downsample_rate(s3enc_handle h, int32_t* rate);
 /* Un-masked frames of an utterance of `length` samples in a batch padded to `n_max`:
  * HuBERT/WavLM forward_padding_mask (hubert_model.py:454-464, WavLM.py:339-349), wav2vec2 conv-length rule

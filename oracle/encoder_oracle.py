@@ -137,7 +137,7 @@ def grouped_conv_same(x_btd: np.ndarray, w: np.ndarray, bias: np.ndarray, G: int
     return out
 
 
-def pos_conv(cfg, W: Dict[str, np.ndarray], x_btd: np.ndarray) -> np.ndarray:
+def pos_conv(cfg, W: Dict[str, np.ndarray], x_btd: np.ndarray, prefix: str = "encoder.pos_conv") -> np.ndarray:
     """``make_conv_pos`` + ``SamePad`` + GELU (wav2vec2_model.py:2937-2953,1797-1808): weight-normed grouped
     Conv1d(D, D, k, padding=k//2, groups=g), drop the last frame when k is even, GELU.  data2vec (``pos_conv_depth`` > 1,
     :2995-3023): a stack of {Conv1d(k = max(3, conv_pos // depth)) -> SamePad -> LayerNorm(no affine) -> GELU}."""
@@ -145,12 +145,12 @@ def pos_conv(cfg, W: Dict[str, np.ndarray], x_btd: np.ndarray) -> np.ndarray:
     if getattr(cfg, "pos_conv_depth", 1) > 1:
         y = x_btd
         for i in range(cfg.pos_conv_depth):
-            y = grouped_conv_same(y, W[f"encoder.pos_conv.{i}.0.weight"].astype(x_btd.dtype),
-                                  W[f"encoder.pos_conv.{i}.0.bias"].astype(x_btd.dtype), G)
+            y = grouped_conv_same(y, W[f"{prefix}.{i}.0.weight"].astype(x_btd.dtype),
+                                  W[f"{prefix}.{i}.0.bias"].astype(x_btd.dtype), G)
             y = gelu(layer_norm(y, None, None))
         return y
-    w = fold_weight_norm(W["encoder.pos_conv.0.weight_g"], W["encoder.pos_conv.0.weight_v"]).astype(x_btd.dtype)
-    return gelu(grouped_conv_same(x_btd, w, W["encoder.pos_conv.0.bias"].astype(x_btd.dtype), G))
+    w = fold_weight_norm(W[f"{prefix}.0.weight_g"], W[f"{prefix}.0.weight_v"]).astype(x_btd.dtype)
+    return gelu(grouped_conv_same(x_btd, w, W[f"{prefix}.0.bias"].astype(x_btd.dtype), G))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -224,10 +224,11 @@ def multihead_attention(cfg, W, prefix: str, x: np.ndarray, valid: Sequence[int]
 # transformer layer + encoder
 # ------------------------------------------------------------------------------------------------
 
-def encoder_layer(cfg, W, l: int, x: np.ndarray, valid, pos_bias, ffn_out: Optional[list] = None) -> np.ndarray:
+def encoder_layer(cfg, W, l: int, x: np.ndarray, valid, pos_bias, ffn_out: Optional[list] = None,
+                  prefix: str = "encoder") -> np.ndarray:
     """``TransformerSentenceEncoderLayer.forward`` (wav2vec2_model.py:3260-3322; WavLM.py:709-774;
     distiller/module.py:191-243).  ``ffn_out`` collects ``layer_result`` = fc2 output before the residual (:3296,3317)."""
-    p = f"encoder.layers.{l}"
+    p = f"{prefix}.layers.{l}"
     dt = x.dtype
     ln1 = (W[f"{p}.self_attn_layer_norm.weight"].astype(dt), W[f"{p}.self_attn_layer_norm.bias"].astype(dt))
     ln2 = (W[f"{p}.final_layer_norm.weight"].astype(dt), W[f"{p}.final_layer_norm.bias"].astype(dt))
@@ -261,6 +262,11 @@ def forward(cfg, weights: Dict[str, np.ndarray], wavs: List[np.ndarray], dtype=n
     family "distiller" (distiller/expert.py:43-52, model.py:178-268, module.py:302-334):
     [feat_final, layer outputs ..., prediction heads ...].
     """
+    if cfg.family == "multires_hubert":  # the U-net of encoders: oracle/multires_oracle.py
+        from . import multires_oracle
+
+        assert selection is None and taps is None
+        return multires_oracle.forward(cfg, weights, wavs, dtype=dtype, n_max=n_max)
     dt = np.dtype(dtype)
     W = {k: v.astype(dt) for k, v in weights.items()}
     lens = [int(len(w)) for w in wavs]

@@ -13,14 +13,15 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libs3enc.so")
 
 S3ENC_MAX_CONV = 16
+S3ENC_MAX_RES = 4
 F32, BF16, F16, F32X3 = 0, 1, 2, 3
 DTYPES = {"fp32": F32, "f32": F32, "float32": F32, "bf16": BF16, "bfloat16": BF16, "fp16": F16, "f16": F16,
           "float16": F16, "fp32x3": F32X3, "f32x3": F32X3, "bf16x3": F32X3}
-FAMILY = {"hubert": 0, "wav2vec2": 1, "wavlm": 2, "distiller": 3}
+FAMILY = {"hubert": 0, "wav2vec2": 1, "wavlm": 2, "distiller": 3, "multires_hubert": 4}
 SEL_HIDDEN, SEL_LAYER_OUT, SEL_FFN_OUT = 0, 1, 2
 SELECTIONS = {None: SEL_HIDDEN, "hidden_states": SEL_HIDDEN, "fairseq_layers": SEL_LAYER_OUT,
               "fairseq_layers_before_residual": SEL_FFN_OUT}
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class S3Config(C.Structure):
@@ -32,6 +33,8 @@ class S3Config(C.Structure):
         ("conv_pos", C.c_int32), ("conv_pos_groups", C.c_int32), ("normalize", C.c_int32), ("rel_pos", C.c_int32),
         ("num_buckets", C.c_int32), ("max_distance", C.c_int32), ("gru_rel_pos", C.c_int32),
         ("compute_dtype", C.c_int32), ("no_feature_layer_norm", C.c_int32), ("pos_conv_depth", C.c_int32), ("wav_norm_eps", C.c_float), ("pred_heads", C.c_int32),
+        ("mr_pairs", C.c_int32), ("mr_ratios", C.c_int32 * (2 * (S3ENC_MAX_RES - 1))),
+        ("mr_layers", C.c_int32 * (2 * S3ENC_MAX_RES - 1)), ("mr_kernel", C.c_int32), ("mr_plain", C.c_int32),
     ]
 
 
@@ -63,6 +66,7 @@ _PROTOS = {
     "s3enc_create": (C.c_int, [C.POINTER(S3Config), C.POINTER(S3Tensor), _I32, _I32, C.POINTER(_VP)]),
     "s3enc_destroy": (C.c_int, [_VP]),
     "s3enc_num_frames": (C.c_int, [_VP, _I64, C.POINTER(_I32)]),
+    "s3enc_num_output_frames": (C.c_int, [_VP, _I64, C.POINTER(_I32)]),
     "s3enc_downsample_rate": (C.c_int, [_VP, C.POINTER(_I32)]),
     "s3enc_valid_frames": (C.c_int, [_VP, _I64, _I64, C.POINTER(_I32)]),
     "s3enc_forward": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(_I64), _I32, _I64, _VP, _I64, _VP]),
@@ -161,4 +165,15 @@ def make_config(cfg, dtype: str) -> S3Config:
     c.pos_conv_depth = int(cfg.pos_conv_depth)
     c.wav_norm_eps = float(cfg.wav_norm_eps)
     c.pred_heads = int(cfg.pred_heads)
+    if cfg.family == "multires_hubert":
+        pairs = cfg.rate_pairs
+        if len(pairs) > S3ENC_MAX_RES - 1:
+            raise S3EncError("too many resolutions")
+        c.mr_pairs = len(pairs)
+        for i, r in enumerate(cfg.label_rate_ratios):
+            c.mr_ratios[i] = int(r)
+        for i, n in enumerate(cfg.block_layers):
+            c.mr_layers[i] = int(n)
+        c.mr_kernel = int(cfg.conv_adapter_kernel)
+        c.mr_plain = int(cfg.use_plain_updownsample)
     return c

@@ -4,6 +4,7 @@
 * wav2vec2 ``{"task_cfg", "model_cfg", "model_weight"}``                          (wav2vec2/convert.py:26-39)
 * WavLM / UniSpeech-SAT ``{"cfg", "model"}``                      (wavlm/expert.py:37-40, unispeech_sat/expert.py:36-39)
 * DistilHuBERT ``{"Config": {"distiller": {...}}, "Distiller": state_dict}``      (distiller/builder.py:41-58,119-122)
+* multires-HuBERT: the HuBERT layout with ``MultiresHubertConfig`` in ``model_cfg``  (multires_hubert/convert.py:21-62)
 
 plus the fairseq layout ``{"cfg": {"task", "model"}, "model"}`` that ``hubert_custom(fairseq=True)`` /
 ``wav2vec2_custom(fairseq=True)`` convert first (hubert/convert.py:22-40, wav2vec2/convert.py:14-24).
@@ -18,7 +19,7 @@ from typing import Dict, Tuple
 
 import numpy as np
 
-from .config import EncoderConfig, config_from_dicts, config_from_distiller
+from .config import EncoderConfig, config_from_dicts, config_from_distiller, config_from_multires
 from .synth import param_shapes
 
 _REQUIRED = {
@@ -26,6 +27,7 @@ _REQUIRED = {
     "wav2vec2": ["task_cfg", "model_cfg", "model_weight"],
     "wavlm": ["cfg", "model"],
     "distiller": ["Config", "Distiller"],
+    "multires_hubert": ["task_cfg", "model_cfg", "model_weight", "dictionaries_symbols"],
 }
 
 
@@ -54,6 +56,9 @@ def load_checkpoint(ckpt: str, family: str) -> Tuple[EncoderConfig, Dict[str, np
     elif family == "distiller":
         cfg = config_from_distiller(_plain(_plain(state["Config"])["distiller"]))
         sd = state["Distiller"]
+    elif family == "multires_hubert":
+        cfg = config_from_multires(_plain(state["model_cfg"]), _plain(state["task_cfg"]))
+        sd = state["model_weight"]
     else:
         cfg = config_from_dicts(family, _plain(state["model_cfg"]), _plain(state["task_cfg"]))
         sd = state["model_weight"]
@@ -89,6 +94,15 @@ def save_checkpoint(path: str, cfg: EncoderConfig, weights: Dict[str, np.ndarray
                  final_dim=cfg.encoder_embed_dim, n_tasks=cfg.pred_heads, task_emb_type="expand-last",
                  out_layer_type="expand-last")
         torch.save({"Config": {"distiller": d}, "Distiller": sd}, path)
+    elif cfg.family == "multires_hubert":
+        R = len(cfg.rate_pairs) + 1
+        bl = cfg.block_layers
+        model_cfg.update(label_rate_ratios=list(cfg.label_rate_ratios), encoder_layers=bl[0],
+                         override_encoder_layers=str(bl[:R] + [bl[2 * R - 2 - i] for i in range(R - 1)]),
+                         conv_adapator_kernal=cfg.conv_adapter_kernel, use_plain_updownsample=cfg.use_plain_updownsample)
+        model_cfg.pop("pos_conv_depth")
+        torch.save({"task_cfg": {"normalize": cfg.normalize, "label_rate": 50.0}, "model_cfg": model_cfg,
+                    "model_weight": sd, "dictionaries_symbols": [["a"] * 8] * R}, path)
     elif cfg.family == "wavlm":
         model_cfg.update(normalize=cfg.normalize, relative_position_embedding=cfg.relative_position_embedding,
                          num_buckets=cfg.num_buckets, max_distance=cfg.max_distance, gru_rel_pos=cfg.gru_rel_pos)

@@ -204,6 +204,21 @@ struct ConvW {
     bool has_bias = false;
 };
 
+// multires-HuBERT (multires_hubert/hubert_model.py:337-530): one TransformerEncoder of the U-net, and a conv adapter
+struct BlockW {
+    std::vector<LayerW> layers;
+    DevBuf eln_g, eln_b;  // the block's own encoder.layer_norm
+};
+struct AdapterConvW {
+    DevBuf w, w3;  // the convolution as a GEMM operand (N, K) in the compute dtype (+ the S3ENC_F32X3 image)
+    DevBuf g, b;   // Fp32GroupNorm(1, D) affine
+};
+struct AdapterW {
+    AdapterConvW up, down;  // ConvTranspose1d(stride = up_rate) / Conv1d(stride = down_rate); plain variants hold one
+    int kind = 0;           // 0 ConvAdapter (both), 1 ConvDownsampler, 2 ConvUpsampler
+    int up_rate = 1, down_rate = 1;
+};
+
 struct ProfRec {
     int kind;
     hipEvent_t a, b;
@@ -232,6 +247,9 @@ struct s3enc_encoder {
     DevBuf ones, zeros;
     DevBuf head_w1, head_b1, head_w2, head_b2, head_w13, head_w23;  // DistilHuBERT prediction heads (+ S3ENC_F32X3 images)
     DevBuf wsum_part;  // persistent partials of s3enc_weighted_sum_backward
+    std::vector<BlockW> mr_blocks;      // S3ENC_MULTIRES: encoders..., middle_encoder, decoders... (execution order)
+    std::vector<AdapterW> mr_adapters;  // downsample_modules[0..R-2], then upsample_modules[0..R-2]
+    DevBuf ws_mr;                       // activation workspace of the U-net behind post_extract_proj
 
     DevBuf ws;      // activation workspace
     DevBuf small;   // tables, stats
@@ -365,6 +383,86 @@ int valid_frames(const s3enc_config& c, long length, long n_max) {
     return (int)v;
 }
 
+// ---- multires-HuBERT frame geometry (mirrors EncoderConfig.multires_plan in s3prl_amd/config.py) ----------------
+struct MrBlockPlan {
+    int layers;
+    long T;       // frames the block runs on
+    int factor;   // repeat_interleave factor of its states (multires_hubert/expert.py:41-47)
+    int adapter;  // index into mr_adapters of the conv adapter applied before the block, -1 for the first
+    long T_in;    // frames entering that adapter
+    long T_sum;   // decoders: min(T, residual frames) of align_size_sum (hubert_model.py:777-783)
+};
+struct MrPlan {
+    std::vector<MrBlockPlan> blocks;
+    long T_out = 0;  // common length every (repeated) state is cut to (expert.py:93-101)
+};
+
+// output frames of a conv adapter on T frames (hubert_model.py:1038-1095,1146-1180,1232-1266): each stage is cut to
+// min(conv length, skip-connection length); kind 0 ConvAdapter, 1 ConvDownsampler, 2 ConvUpsampler
+long mr_adapter_frames(int k, long T, int up, int down, int kind) {
+    long n = T;
+    if (kind != 1) n = std::min<long>((long)up * T + k - 1, (long)up * T);
+    if (kind != 2) {
+        const long ld = (n + 2 * ((k - 1) / 2) - k) / down + 1;
+        const long n2 = std::min(ld, (n + down - 1) / down);
+        n = kind == 0 ? std::min(n2, ((long)up * T + down - 1) / down) : n2;
+    }
+    return n;
+}
+
+void mr_plan(const s3enc_config& c, long T0, MrPlan& plan) {
+    const int R = c.mr_pairs + 1, k = c.mr_kernel;
+    long ds[S3ENC_MAX_RES], lcm = 1;
+    ds[0] = 1;
+    for (int i = 0; i < c.n_conv; ++i) ds[0] *= c.conv_stride[i];
+    for (int i = 0; i < R - 1; ++i) ds[i + 1] = ds[i] * c.mr_ratios[2 * i + 1] / c.mr_ratios[2 * i];  // hubert_model.py:512-533
+    for (int i = 0; i < R; ++i) {
+        long a = lcm, b = ds[i];
+        while (b) {
+            const long r = a % b;
+            a = b;
+            b = r;
+        }
+        lcm = lcm / a * ds[i];
+    }
+    int upf[S3ENC_MAX_RES], rev[S3ENC_MAX_RES];
+    for (int i = 0; i < R; ++i) upf[i] = (int)(lcm / ds[R - 1 - i]);  // (sic) the expert reverses the list, expert.py:44-45
+    for (int i = 0; i + 1 < R; ++i) rev[i] = upf[R - 2 - i];           // upsample_factor[::-1][1:]
+    plan.blocks.clear();
+    long T = T0, encT[S3ENC_MAX_RES];
+    int ad = -1;
+    long t_in = 0;
+    for (int i = 0; i < R - 1; ++i) {
+        plan.blocks.push_back({c.mr_layers[i], T, upf[i], ad, t_in, T});
+        encT[i] = T;
+        ad = i;
+        t_in = T;
+        T = mr_adapter_frames(k, T, c.mr_ratios[2 * i], c.mr_ratios[2 * i + 1], c.mr_plain ? 1 : 0);
+    }
+    plan.blocks.push_back({c.mr_layers[R - 1], T, upf[R - 1], ad, t_in, T});
+    for (int i = 0; i < R - 1; ++i) {
+        t_in = T;
+        T = mr_adapter_frames(k, T, c.mr_ratios[2 * i + 1], c.mr_ratios[2 * i], c.mr_plain ? 2 : 0);
+        const long res = encT[R - 2 - i];
+        plan.blocks.push_back({c.mr_layers[R + i], T, rev[i], R - 1 + i, t_in, std::min(T, res)});
+        T = std::min(T, res);
+    }
+    plan.T_out = -1;
+    for (const auto& b : plan.blocks) {
+        const long a = b.T * b.factor, p2 = (b.T + (b.T & 1)) * b.factor;  // outputs; layer inputs are padded to even T
+        const long m = std::min(a, p2);
+        if (plan.T_out < 0 || m < plan.T_out) plan.T_out = m;
+    }
+}
+
+long output_frames(const s3enc_config& c, long n_samples) {
+    const long T = conv_len(c, n_samples, c.n_conv);
+    if (c.family != S3ENC_MULTIRES || T < 1) return T;
+    MrPlan plan;
+    mr_plan(c, T, plan);
+    return plan.T_out;
+}
+
 // WavLM bucket table (wavlm/modules.py:418-462): table[h][rel + R] = E[bucket(rel)][h] for rel = key - query in [-R, R]
 void build_rel_table(const s3enc_config& c, const std::vector<float>& emb, int R, std::vector<float>& table) {
     const int H = c.heads, nb = c.num_buckets / 2, max_exact = nb / 2;
@@ -390,7 +488,25 @@ void build_rel_table(const s3enc_config& c, const std::vector<float>& emb, int R
 }
 
 int check_config(const s3enc_config& c) {
-    if (c.family < 0 || c.family > 3) return fail("config: unknown family");
+    if (c.family < 0 || c.family > 4) return fail("config: unknown family");
+    if (c.family == S3ENC_MULTIRES) {
+        if (c.mr_pairs < 1 || c.mr_pairs > S3ENC_MAX_RES - 1) return fail("config: mr_pairs out of range");
+        const int k = c.mr_kernel;
+        if (k < 1 || k > 15 || !(k & 1)) return fail("config: mr_kernel must be odd and <= 15");
+        int total = 0;
+        for (int i = 0; i < 2 * c.mr_pairs + 1; ++i) {
+            if (c.mr_layers[i] < 1) return fail("config: every multires block needs at least one layer");
+            total += c.mr_layers[i];
+        }
+        if (total != c.encoder_layers) return fail("config: encoder_layers must equal the sum of mr_layers");
+        for (int i = 0; i < 2 * c.mr_pairs; ++i) {
+            const int r = c.mr_ratios[i];
+            if (r < 1 || r > 4 || (k - 1) % r) return fail("config: every multires rate must divide mr_kernel - 1");
+            if (c.mr_plain && !(i & 1) && r != 1) return fail("config: mr_plain needs rate pairs of the form (1, d)");
+        }
+        if (c.rel_pos || c.pred_heads || c.pos_conv_depth > 1 || c.no_feature_layer_norm)
+            return fail("config: multires-HuBERT takes none of the WavLM / DistilHuBERT / data2vec options");
+    }
     if (c.pred_heads < 0 || c.pred_heads > 16) return fail("config: pred_heads out of range");
     if (c.pred_heads && c.family != S3ENC_DISTILLER) return fail("config: pred_heads is a DistilHuBERT feature");
     if (c.n_conv < 2 || c.n_conv > S3ENC_MAX_CONV) return fail("config: n_conv out of range");
@@ -448,6 +564,8 @@ int s3enc_create(const s3enc_config* cfg, const s3enc_tensor* tensors, int32_t n
     e->es = e->dtype == F32 ? 4 : 2;
     const s3enc_config& c = e->cfg;
     const int C = c.conv_dim, D = c.embed_dim, F = c.ffn_dim, H = c.heads;
+    const bool multires = c.family == S3ENC_MULTIRES;
+    const std::string enc0 = multires ? "encoders.0" : "encoder";  // only the first block keeps its positional conv
     std::string err;
     std::vector<float> t, t2;
 #define GET(name, n, vec)                  \
@@ -544,8 +662,8 @@ int s3enc_create(const s3enc_config* cfg, const s3enc_tensor* tensors, int32_t n
     } else {
         const int K = c.conv_pos, G = c.conv_pos_groups, Dg = D / G;
         std::vector<float> g, v;
-        GET("encoder.pos_conv.0.weight_g", K, g);
-        GET("encoder.pos_conv.0.weight_v", (long)D * Dg * K, v);
+        GET(enc0 + ".pos_conv.0.weight_g", K, g);
+        GET(enc0 + ".pos_conv.0.weight_v", (long)D * Dg * K, v);
         std::vector<double> nrm(K, 0.0);
         for (long i = 0; i < (long)D * Dg; ++i)
             for (int k = 0; k < K; ++k) nrm[k] += (double)v[i * K + k] * v[i * K + k];
@@ -555,20 +673,20 @@ int s3enc_create(const s3enc_config* cfg, const s3enc_tensor* tensors, int32_t n
         pack_posconv(v, D, G, K, e->dtype, t2);
         UP(upload_cvt(e->pos_w, t2, e->dtype));
         if (e->x3) UP(upload_posconv_x3(e->pos_w3, v, D, G, K));
-        GET("encoder.pos_conv.0.bias", D, t);
+        GET(enc0 + ".pos_conv.0.bias", D, t);
         UP(upload_f32(e->pos_b, t));
     }
-    GET("encoder.layer_norm.weight", D, t);
-    UP(upload_f32(e->eln_g, t));
-    GET("encoder.layer_norm.bias", D, t);
-    UP(upload_f32(e->eln_b, t));
+    if (!multires) {
+        GET("encoder.layer_norm.weight", D, t);
+        UP(upload_f32(e->eln_g, t));
+        GET("encoder.layer_norm.bias", D, t);
+        UP(upload_f32(e->eln_b, t));
+    }
 
     // ---- transformer layers ----
-    e->layers.resize(c.encoder_layers);
     const float qscale = 1.0f / std::sqrt((float)(D / H));
-    for (int l = 0; l < c.encoder_layers; ++l) {
-        const std::string p = "encoder.layers." + std::to_string(l);
-        LayerW& L = e->layers[l];
+    // one TransformerSentenceEncoderLayer named `p` (…layers.N); returns non-zero after fail() (e is already deleted)
+    auto load_layer = [&](const std::string& p, LayerW& L) -> int {
         std::vector<float> w(3L * D * D), bb(3L * D);
         const char* names[3] = {"q_proj", "k_proj", "v_proj"};
         for (int s = 0; s < 3; ++s) {
@@ -611,6 +729,84 @@ int s3enc_create(const s3enc_config* cfg, const s3enc_tensor* tensors, int32_t n
             UP(upload_f32(L.grep_b, t));
             GET(p + ".self_attn.grep_a", H, t);
             UP(upload_f32(L.grep_a, t));
+        }
+        return 0;
+    };
+    if (!multires) {
+        e->layers.resize(c.encoder_layers);
+        for (int l = 0; l < c.encoder_layers; ++l)
+            if (load_layer("encoder.layers." + std::to_string(l), e->layers[l])) return 1;
+    } else {
+        // U-net blocks in execution order (hubert_model.py:399-507) and the conv adapters between them
+        const int R = c.mr_pairs + 1, NB = 2 * R - 1, k = c.mr_kernel;
+        e->mr_blocks.resize(NB);
+        for (int bi = 0; bi < NB; ++bi) {
+            const std::string bp = bi < R - 1 ? "encoders." + std::to_string(bi)
+                                 : bi == R - 1 ? std::string("middle_encoder") : "decoders." + std::to_string(bi - R);
+            BlockW& bw = e->mr_blocks[bi];
+            GET(bp + ".layer_norm.weight", D, t);
+            UP(upload_f32(bw.eln_g, t));
+            GET(bp + ".layer_norm.bias", D, t);
+            UP(upload_f32(bw.eln_b, t));
+            bw.layers.resize(c.mr_layers[bi]);
+            for (int l = 0; l < c.mr_layers[bi]; ++l)
+                if (load_layer(bp + ".layers." + std::to_string(l), bw.layers[l])) return 1;
+        }
+        // A conv over all D channels becomes a GEMM whose A rows are k_eff * D contiguous elements of a zero-bordered
+        // frame buffer (kernels.h, PadCopyParams):
+        //   Conv1d(D, D, k, stride s, padding (k-1)/2), weight (co, ci, j):  W'[co][j*D + ci], row t starts at frame t*s - pad
+        //   ConvTranspose1d(D, D, k, stride s), weight (ci, co, j): s interleaved stride-1 convs of KT = ceil(k/s) taps —
+        //     out[s*q + r] = sum_m x[q - m] . w[:, :, r + s*m]  ->  W'[r*D + co][j'*D + ci] = w[ci][co][r + s*(KT-1-j')]
+        //     (0 where that tap is >= k), row q starts at frame q - (KT-1); the (Q, s*D) output IS the (s*Q, D) sequence
+        auto load_conv = [&](const std::string& cp, bool transposed, int stride, AdapterConvW& cw) -> int {
+            std::vector<float> w, pk;
+            GET(cp + ".0.weight", (long)D * D * k, w);
+            long N, K;
+            if (!transposed) {
+                N = D;
+                K = (long)k * D;
+                pk.assign((size_t)N * K, 0.f);
+                for (int co = 0; co < D; ++co)
+                    for (int ci = 0; ci < D; ++ci)
+                        for (int j = 0; j < k; ++j) pk[(long)co * K + (long)j * D + ci] = w[((long)co * D + ci) * k + j];
+            } else {
+                const int KT = (k + stride - 1) / stride;
+                N = (long)stride * D;
+                K = (long)KT * D;
+                pk.assign((size_t)N * K, 0.f);
+                for (int r = 0; r < stride; ++r)
+                    for (int jp = 0; jp < KT; ++jp) {
+                        const int tap = r + stride * (KT - 1 - jp);
+                        if (tap >= k) continue;
+                        for (int co = 0; co < D; ++co)
+                            for (int ci = 0; ci < D; ++ci)
+                                pk[((long)r * D + co) * K + (long)jp * D + ci] = w[((long)ci * D + co) * k + tap];
+                    }
+            }
+            UP(upload_cvt(cw.w, pk, e->dtype));
+            if (e->x3) UP(upload_x3(cw.w3, pk, N, K));
+            GET(cp + ".2.weight", D, t);
+            UP(upload_f32(cw.g, t));
+            GET(cp + ".2.bias", D, t);
+            UP(upload_f32(cw.b, t));
+            return 0;
+        };
+        e->mr_adapters.resize(2 * (R - 1));
+        for (int i = 0; i < R - 1; ++i) {
+            const int u = c.mr_ratios[2 * i], d = c.mr_ratios[2 * i + 1];
+            AdapterW& dn = e->mr_adapters[i];            // downsample_modules[i]: label_rate (u, d)
+            AdapterW& upm = e->mr_adapters[R - 1 + i];   // upsample_modules[i]: the inverted pair (d, u) (:474-507)
+            dn.kind = c.mr_plain ? 1 : 0;
+            dn.up_rate = u;
+            dn.down_rate = d;
+            upm.kind = c.mr_plain ? 2 : 0;
+            upm.up_rate = d;
+            upm.down_rate = u;
+            const std::string dp = "downsample_modules." + std::to_string(i), upp = "upsample_modules." + std::to_string(i);
+            if (dn.kind != 1 && load_conv(dp + ".upsample_conv", true, dn.up_rate, dn.up)) return 1;
+            if (load_conv(dp + ".downsample_conv", false, dn.down_rate, dn.down)) return 1;
+            if (load_conv(upp + ".upsample_conv", true, upm.up_rate, upm.up)) return 1;
+            if (upm.kind != 2 && load_conv(upp + ".downsample_conv", false, upm.down_rate, upm.down)) return 1;
         }
     }
     if (c.rel_pos) {
@@ -666,6 +862,11 @@ int s3enc_num_frames(s3enc_handle h, int64_t n_samples, int32_t* T) {
     *T = (int32_t)conv_len(h->cfg, n_samples, h->cfg.n_conv);
     return 0;
 }
+int s3enc_num_output_frames(s3enc_handle h, int64_t n_samples, int32_t* T) {
+    if (!h || !T) return fail("s3enc_num_output_frames: null argument");
+    *T = (int32_t)output_frames(h->cfg, n_samples);
+    return 0;
+}
 int s3enc_downsample_rate(s3enc_handle h, int32_t* rate) {
     if (!h || !rate) return fail("s3enc_downsample_rate: null argument");
     int r = 1;
@@ -704,6 +905,7 @@ struct FwdOpts {
 };
 
 int num_states(const s3enc_config& c, int selection) {
+    if (c.family == S3ENC_MULTIRES) return c.encoder_layers + 2 * c.mr_pairs + 1;  // per block: layer inputs + its output
     if (selection == S3ENC_SEL_HIDDEN) return c.encoder_layers + 1 + (c.family == S3ENC_DISTILLER ? c.pred_heads : 0);
     return c.encoder_layers;
 }
@@ -751,16 +953,411 @@ struct Sink {
     }
 };
 
+// ---- multires-HuBERT behind post_extract_proj (multires_hubert/hubert_model.py:786-822) -------------------------------
+// x (B, T0, D) fp32 with the padded frames zeroed -> encoders[i] -> conv adapter (down) ... middle_encoder (+ its input) ...
+// conv adapter (up) -> decoders[i] (+ the matching encoder's output).  Every block's layer inputs and its output are
+// states; each is written to its (B, T_out, D) slot with its frames repeated `factor` times (expert.py:26-27,93-101).
+// The blocks run the same GEMM / attention / LayerNorm kernels as the single-resolution encoders; the adapter
+// convolutions are GEMMs over zero-bordered frame buffers, their GroupNorm / GELU / skip passes are adapter.hip.
+int multires_tail(s3enc_handle e, hipStream_t st, int B, const MrPlan& plan, const std::vector<const int*>& d_valid, float* xproj,
+                  void* out, long layer_stride, int out_dtype) {
+    const s3enc_config& c = e->cfg;
+    const int D = c.embed_dim, F = c.ffn_dim, H = c.heads;
+    const int dt = e->dtype, es = e->es;
+    const bool prel = c.layer_norm_first != 0;
+    const int R = c.mr_pairs + 1, NB = 2 * R - 1, k = c.mr_kernel, PADR = k - 1;
+    const bool out16 = out_dtype != F32;
+    const float scale = std::sqrt(0.4f);  // sqrt(residual_scale), hubert_model.py:429,1036
+
+    // capacities: frames of the widest block, rows of the widest zero-bordered operand, frames of the longest conv output
+    long Tc = 0, Pc = 0, Lc = 0;
+    for (const auto& bp : plan.blocks) {
+        Tc = std::max(Tc, bp.T);
+        if (bp.adapter < 0) continue;
+        const AdapterW& aw = e->mr_adapters[bp.adapter];
+        long rows = bp.T_in;
+        Pc = std::max(Pc, rows + 2 * PADR);
+        if (aw.kind != 1) {
+            Lc = std::max(Lc, (rows + (k - 1) / aw.up_rate) * aw.up_rate);
+            rows *= aw.up_rate;
+            Pc = std::max(Pc, rows + 2 * PADR);
+        }
+        if (aw.kind != 2) Lc = std::max(Lc, (rows - 1) / aw.down_rate + 1);
+    }
+    const long Mc = (long)B * Tc;
+    float *hA, *hB, *yM, *bufX, *tmp1, *tmp2, *pad32[2], *convout, *res[S3ENC_MAX_RES] = {};
+    void *xT, *qkv, *attn, *hbuf, *pad16[2] = {};
+    double* gpart;
+    for (int pass = 0; pass < 2; ++pass) {
+        Bump wb(pass ? e->ws_mr.p : nullptr);
+        hA = (float*)wb.take((size_t)Mc * D * 4);
+        hB = (float*)wb.take((size_t)Mc * D * 4);
+        yM = (float*)wb.take((size_t)Mc * D * 4);
+        bufX = (float*)wb.take((size_t)Mc * D * 4);
+        tmp1 = (float*)wb.take((size_t)Mc * D * 4);
+        tmp2 = (float*)wb.take((size_t)Mc * D * 4);
+        xT = wb.take((size_t)Mc * D * 4);
+        qkv = wb.take((size_t)Mc * 3 * D * es);
+        attn = wb.take((size_t)Mc * D * es);
+        hbuf = wb.take((size_t)Mc * F * es);
+        for (int i = 0; i < R - 1; ++i) res[i] = (float*)wb.take((size_t)B * plan.blocks[i].T * D * 4);
+        for (int i = 0; i < 2; ++i) {
+            pad32[i] = (float*)wb.take((size_t)B * Pc * D * 4);
+            if (dt != F32) pad16[i] = wb.take((size_t)B * Pc * D * 2);
+        }
+        convout = (float*)wb.take((size_t)B * Lc * D * 4);
+        gpart = (double*)wb.take((size_t)B * GS_BLOCKS * 2 * 8);
+        if (!pass) HIP_TRY(e->ws_mr.ensure_on_stream(wb.off + 4096, st));
+    }
+
+    int si = 0;
+    // a state (B, T, D) -> slot si of the caller's slab at the finest frame rate
+    auto emit = [&](const float* x, long T, int factor) -> int {
+        float* o32 = out16 ? nullptr : (float*)out + (long)si * layer_stride;
+        void* o16 = out16 ? (void*)((u16*)out + (long)si * layer_stride) : nullptr;
+        {
+            Prof pr(e, st, "emit_state", 0, (double)B * plan.T_out * D * (4.0 / factor + (out16 ? 2 : 4)));
+            HIP_TRY(launch_emit_upsampled(out16 ? dt : (int)F32, x, T * D, factor, B, (int)plan.T_out, D, o32, o16, st));
+        }
+        if (si < (int)e->layer_events.size()) HIP_TRY(hipEventRecord(e->layer_events[si], st));
+        ++si;
+        return 0;
+    };
+
+    // one TransformerEncoder of the U-net (wav2vec2_model.py:3046-3121 with skip_pos_conv / override_encoder_layer):
+    // x (B, T, D) fp32, padded frames zero (the producer wrote them so); the block's output lands in y_out
+    auto run_block = [&](int bi, float* x, float* y_out) -> int {
+        BlockW& bw = e->mr_blocks[bi];
+        const MrBlockPlan& bp = plan.blocks[bi];
+        const long T = bp.T, M = (long)B * T;
+        const double gM = (double)M;
+        const int NLb = (int)bw.layers.size();
+        float* cur = x;
+        auto pick = [&](const float* busy) { return busy == hA ? hB : hA; };
+        if (bi == 0) {  // only encoders[0] keeps the positional conv (hubert_model.py:434-449)
+            PosConvParams p{};
+            p.x = x;
+            p.w = e->x3 ? e->pos_w3.p : e->pos_w.p;
+            p.bias = (const float*)e->pos_b.p;
+            p.out = hA;
+            p.B = B;
+            p.T = (int)T;
+            p.D = D;
+            p.G = c.conv_pos_groups;
+            p.K = c.conv_pos;
+            Prof pr(e, st, "posconv", 2.0 * gM * D * (D / p.G) * p.K, gM * D * 8 + (double)D * (D / p.G) * p.K * 4);
+            HIP_TRY(e->x3 ? launch_posconv16(3, p, st) : (dt == F32 ? launch_posconv(p, st) : launch_posconv16(dt, p, st)));
+            cur = hA;
+        }
+        if (!prel) {
+            float* h0 = pick(cur);
+            Prof pr(e, st, "layernorm:enc", 0, gM * D * (8 + (dt == F32 ? 0 : es)));
+            HIP_TRY(launch_layernorm(dt, cur, (const float*)bw.eln_g.p, (const float*)bw.eln_b.p, M, D, 0, h0,
+                                     dt == F32 ? nullptr : xT, st));
+            cur = h0;
+        }
+        if (emit(cur, T, bp.factor)) return 1;  // the input of the block's first layer
+        for (int l = 0; l < NLb; ++l) {
+            LayerW& Lw = bw.layers[l];
+            const bool lastl = l == NLb - 1;
+            const void* a_in;
+            if (prel) {
+                Prof pr(e, st, "layernorm:ln1", 0, gM * D * (4 + es));
+                HIP_TRY(launch_layernorm(dt, cur, (const float*)Lw.ln1g.p, (const float*)Lw.ln1b.p, M, D, 0,
+                                         dt == F32 ? (float*)xT : nullptr, dt == F32 ? nullptr : xT, st));
+                a_in = xT;
+            } else {
+                a_in = dt == F32 ? (const void*)cur : (const void*)xT;
+            }
+            {
+                GemmParams g{};
+                g.A = a_in;
+                g.lda = D;
+                g.W = Lw.wqkv.p;
+                g.W_x3 = Lw.wqkv3.p;
+                g.bias = (const float*)Lw.bqkv.p;
+                g.M = (int)M;
+                g.N = 3 * D;
+                g.K = D;
+                g.batches = 1;
+                g.ldo = 3 * D;
+                if (dt == F32) g.out32 = (float*)qkv; else g.out16 = qkv;
+                Prof pr(e, st, "gemm:qkv", 2.0 * gM * 3 * D * D, (gM * D + 3.0 * D * D + gM * 3 * D) * es);
+                HIP_TRY(launch_gemm(dt, g, st));
+            }
+            {
+                AttnParams a{};
+                a.qkv = qkv;
+                a.out = attn;
+                a.valid = d_valid[bi];
+                a.B = B;
+                a.T = (int)T;
+                a.H = H;
+                Prof pr(e, st, "attention", 4.0 * B * H * (double)T * T * 64, gM * 4 * D * es);
+                HIP_TRY(launch_attention(e->x3 ? 3 : dt, a, st));
+            }
+            {
+                GemmParams g{};
+                g.A = attn;
+                g.lda = D;
+                g.W = Lw.wo.p;
+                g.W_x3 = Lw.wo3.p;
+                g.bias = (const float*)Lw.bo.p;
+                g.M = (int)M;
+                g.N = D;
+                g.K = D;
+                g.batches = 1;
+                g.ldo = D;
+                g.residual = cur;
+                g.out32 = tmp1;
+                Prof pr(e, st, "gemm:out_proj", 2.0 * gM * D * D, (gM * D + (double)D * D) * es + gM * D * 8);
+                HIP_TRY(launch_gemm(dt, g, st));
+            }
+            const float* ffn_res;
+            const void* ffn_in;
+            if (prel) {
+                Prof pr(e, st, "layernorm:ln2", 0, gM * D * (4 + es));
+                HIP_TRY(launch_layernorm(dt, tmp1, (const float*)Lw.ln2g.p, (const float*)Lw.ln2b.p, M, D, 0,
+                                         dt == F32 ? (float*)xT : nullptr, dt == F32 ? nullptr : xT, st));
+                ffn_res = tmp1;
+                ffn_in = xT;
+            } else {
+                Prof pr(e, st, "layernorm:ln1", 0, gM * D * (8 + (dt == F32 ? 0 : es)));
+                HIP_TRY(launch_layernorm(dt, tmp1, (const float*)Lw.ln1g.p, (const float*)Lw.ln1b.p, M, D, 0, tmp2,
+                                         dt == F32 ? nullptr : xT, st));
+                ffn_res = tmp2;
+                ffn_in = dt == F32 ? (const void*)tmp2 : (const void*)xT;
+            }
+            {
+                GemmParams g{};
+                g.A = ffn_in;
+                g.lda = D;
+                g.W = Lw.w1.p;
+                g.W_x3 = Lw.w13.p;
+                g.bias = (const float*)Lw.b1.p;
+                g.M = (int)M;
+                g.N = F;
+                g.K = D;
+                g.batches = 1;
+                g.act = 1;
+                g.ldo = F;
+                if (dt == F32) g.out32 = (float*)hbuf; else g.out16 = hbuf;
+                Prof pr(e, st, "gemm:fc1", 2.0 * gM * F * D, (gM * D + (double)F * D + gM * F) * es);
+                HIP_TRY(launch_gemm(dt, g, st));
+            }
+            float* nxt = (!prel && lastl) ? y_out : pick(cur);
+            {
+                GemmParams g{};
+                g.A = hbuf;
+                g.lda = F;
+                g.W = Lw.w2.p;
+                g.W_x3 = Lw.w23.p;
+                g.bias = (const float*)Lw.b2.p;
+                g.M = (int)M;
+                g.N = D;
+                g.K = F;
+                g.batches = 1;
+                g.ldo = D;
+                g.residual = ffn_res;
+                g.out32 = prel ? nxt : tmp1;
+                Prof pr(e, st, "gemm:fc2", 2.0 * gM * D * F, (gM * F + (double)D * F) * es + gM * D * 8);
+                HIP_TRY(launch_gemm(dt, g, st));
+            }
+            if (!prel) {
+                Prof pr(e, st, "layernorm:ln2", 0, gM * D * (8 + (dt == F32 ? 0 : es)));
+                HIP_TRY(launch_layernorm(dt, tmp1, (const float*)Lw.ln2g.p, (const float*)Lw.ln2b.p, M, D, 0, nxt,
+                                         dt == F32 ? nullptr : xT, st));
+            }
+            cur = nxt;
+            // post-LN: the layer output is the next layer's input / the block output; pre-LN: the last stream is not a state
+            if (!prel || !lastl)
+                if (emit(cur, T, bp.factor)) return 1;
+        }
+        if (prel) {  // encoder.layer_norm on the last residual stream (wav2vec2_model.py:3049-3050): the block output
+            {
+                Prof pr(e, st, "layernorm:enc", 0, gM * D * 8);
+                HIP_TRY(launch_layernorm(F32, cur, (const float*)bw.eln_g.p, (const float*)bw.eln_b.p, M, D, 0, y_out, nullptr, st));
+            }
+            if (emit(y_out, T, bp.factor)) return 1;
+        }
+        return 0;
+    };
+
+    // One convolution + GroupNorm(1, D) statistics of a conv adapter stage: A rows are k_eff * D contiguous elements of the
+    // zero-bordered buffer (lead = PADR rows), output (B, L, D) fp32 in convout; returns L through `frames`
+    auto run_conv = [&](const AdapterConvW& cw, bool transposed, int stride, int which, long rows, long* frames) -> int {
+        const long total = rows + 2 * PADR;
+        GemmParams g{};
+        const char* base = dt == F32 ? (const char*)pad32[which] : (const char*)pad16[which];
+        long Mrows;
+        if (transposed) {
+            const int KT = (k + stride - 1) / stride;
+            Mrows = rows + (k - 1) / stride;  // Q; the (Q, stride * D) output is the (stride * Q, D) sequence
+            g.A = base + (size_t)(PADR - (KT - 1)) * D * es;
+            g.lda = D;
+            g.N = stride * D;
+            g.K = KT * D;
+            *frames = Mrows * stride;
+        } else {
+            const int pd = (k - 1) / 2;
+            Mrows = (rows + 2 * pd - k) / stride + 1;
+            g.A = base + (size_t)(PADR - pd) * D * es;
+            g.lda = (long)stride * D;
+            g.N = D;
+            g.K = k * D;
+            *frames = Mrows;
+        }
+        g.a_bs = total * D;
+        g.W = cw.w.p;
+        g.W_x3 = cw.w3.p;
+        g.M = (int)Mrows;
+        g.batches = B;
+        g.out32 = convout;
+        g.ldo = g.N;
+        g.o_bs = *frames * D;
+        {
+            Prof pr(e, st, "gemm:adapter", 2.0 * B * Mrows * g.N * g.K,
+                    ((double)B * total * D + (double)g.N * g.K) * es + (double)B * *frames * D * 4);
+            HIP_TRY(launch_gemm(dt, g, st));
+        }
+        Prof pr(e, st, "adapter_stats", 0, (double)B * *frames * D * 4);
+        HIP_TRY(launch_group1_stats(convout, *frames * D, *frames * D, B, gpart, st));
+        return 0;
+    };
+
+    // a conv adapter (hubert_model.py:1038-1078 ConvAdapter, :1146-1167 ConvDownsampler, :1232-1250 ConvUpsampler):
+    // input rows a[t] (+ b2[t]) of T_in frames -> bufX (B, n_out, D) fp32 with the frames >= zero_next[b] zeroed
+    auto run_adapter = [&](const AdapterW& aw, const float* a, long a_bs, const float* b2, long b_bs, long T_in, const int* zero_next,
+                           long n_expect) -> int {
+        {
+            PadCopyParams pc{};
+            pc.a = a;
+            pc.a_bs = a_bs;
+            pc.b = b2;
+            pc.b_bs = b_bs;
+            pc.B = B;
+            pc.rows = (int)T_in;
+            pc.D = D;
+            pc.lead = PADR;
+            pc.total = (int)(T_in + 2 * PADR);
+            pc.out32 = pad32[0];
+            pc.out16 = pad16[0];
+            Prof pr(e, st, "adapter_pad", 0, (double)B * T_in * D * (b2 ? 8 : 4) + (double)B * pc.total * D * (4 + (dt == F32 ? 0 : 2)));
+            HIP_TRY(launch_pad_copy(dt, pc, st));
+        }
+        const long total0 = T_in + 2 * PADR;
+        long rows = T_in, frames = 0;
+        int cur = 0;  // operand buffer holding the current stage's input
+        AdapterApplyParams ap{};
+        ap.conv = convout;
+        ap.partial = gpart;
+        ap.scale = scale;
+        ap.B = B;
+        ap.D = D;
+        ap.fast_gelu = e->x3;
+        if (aw.kind != 1) {  // upsample_conv + skip from repeat_interleave(x, up)
+            if (run_conv(aw.up, true, aw.up_rate, cur, rows, &frames)) return 1;
+            const long n1 = std::min(frames, rows * aw.up_rate);
+            ap.conv_bs = frames * D;
+            ap.count = (double)frames * D;
+            ap.gamma = (const float*)aw.up.g.p;
+            ap.beta = (const float*)aw.up.b.p;
+            ap.r1 = pad32[0] + (long)PADR * D;
+            ap.r1_bs = total0 * D;
+            ap.r1_mul = 1;
+            ap.r1_div = aw.up_rate;
+            ap.r2 = nullptr;
+            ap.rows = (int)n1;
+            const bool fin = aw.kind == 2;
+            ap.lead = fin ? 0 : PADR;
+            ap.total = (int)(fin ? n1 : n1 + 2 * PADR);
+            ap.zero_from = fin ? zero_next : nullptr;
+            ap.out32 = fin ? bufX : pad32[1];
+            ap.out16 = fin ? nullptr : pad16[1];
+            Prof pr(e, st, "adapter_apply", 0, (double)B * n1 * D * 12);
+            HIP_TRY(launch_adapter_apply(dt, ap, st));
+            rows = n1;
+            cur = 1;
+        }
+        if (aw.kind != 2) {  // downsample_conv + skip x[::down] (+ highway repeat_interleave(x0, up)[::down])
+            if (run_conv(aw.down, false, aw.down_rate, cur, rows, &frames)) return 1;
+            const long n2 = std::min(frames, (rows + aw.down_rate - 1) / aw.down_rate);
+            const long n3 = aw.kind == 0 ? std::min(n2, (T_in * aw.up_rate + aw.down_rate - 1) / aw.down_rate) : n2;
+            ap.conv_bs = frames * D;
+            ap.count = (double)frames * D;
+            ap.gamma = (const float*)aw.down.g.p;
+            ap.beta = (const float*)aw.down.b.p;
+            ap.r1 = pad32[cur] + (long)PADR * D;
+            ap.r1_bs = (rows + 2 * PADR) * D;
+            ap.r1_mul = aw.down_rate;
+            ap.r1_div = 1;
+            if (aw.kind == 0) {
+                ap.r2 = pad32[0] + (long)PADR * D;
+                ap.r2_bs = total0 * D;
+                ap.r2_mul = aw.down_rate;
+                ap.r2_div = aw.up_rate;
+            } else {
+                ap.r2 = nullptr;
+            }
+            ap.rows = (int)n3;
+            ap.lead = 0;
+            ap.total = (int)n3;
+            ap.zero_from = zero_next;
+            ap.out32 = bufX;
+            ap.out16 = nullptr;
+            Prof pr(e, st, "adapter_apply", 0, (double)B * n3 * D * (aw.kind == 0 ? 16 : 12));
+            HIP_TRY(launch_adapter_apply(dt, ap, st));
+            rows = n3;
+        }
+        if (rows != n_expect) return fail("multires: adapter length does not match the plan (internal error)");
+        return 0;
+    };
+
+    float* x = xproj;
+    for (int bi = 0; bi < NB; ++bi) {
+        const MrBlockPlan& bp = plan.blocks[bi];
+        if (bp.adapter >= 0) {
+            const AdapterW& aw = e->mr_adapters[bp.adapter];
+            const float *a, *b2 = nullptr;
+            long a_bs, b_bs = 0;
+            if (bi <= R - 1) {  // an encoder's output -> downsample_modules[bi - 1]
+                a = res[bi - 1];
+                a_bs = plan.blocks[bi - 1].T * D;
+            } else if (bi == R) {  // x = x + middle_encoder(x) (hubert_model.py:801-802): x is the middle block's zeroed input
+                a = bufX;
+                a_bs = plan.blocks[bi - 1].T * D;
+                b2 = yM;
+                b_bs = a_bs;
+            } else {  // align_size_sum(decoder output, the matching encoder output) (:816)
+                const int ri = R - 2 - (bi - 1 - R);
+                a = yM;
+                a_bs = plan.blocks[bi - 1].T * D;
+                b2 = res[ri];
+                b_bs = plan.blocks[ri].T * D;
+            }
+            if (run_adapter(aw, a, a_bs, b2, b_bs, bp.T_in, d_valid[bi], bp.T)) return 1;
+            x = bufX;
+        }
+        if (run_block(bi, x, bi < R - 1 ? res[bi] : yM)) return 1;
+    }
+    if (si != num_states(c, S3ENC_SEL_HIDDEN)) return fail("multires: state count mismatch (internal error)");
+    return 0;
+}
+
 int forward_impl(s3enc_handle e, const float* const* wav_ptrs_host, const int64_t* lengths, int32_t B, int64_t n_max_in,
                  const FwdOpts& fo, void* out, int64_t layer_stride, hipStream_t st) {
     const s3enc_config& c = e->cfg;
     const int C = c.conv_dim, D = c.embed_dim, F = c.ffn_dim, H = c.heads, NL = c.encoder_layers;
     const int dt = e->dtype, es = e->es;
     const bool dist = c.family == S3ENC_DISTILLER;
+    const bool mr = c.family == S3ENC_MULTIRES;
     const int NH = dist ? c.pred_heads : 0;
     if (B <= 0) return fail("s3enc_forward: B must be positive");
     if (fo.selection < 0 || fo.selection > 2) return fail("s3enc_forward: unknown selection");
-    if (dist && fo.selection != S3ENC_SEL_HIDDEN) return fail("s3enc_forward: DistilHuBERT has one selection (its hidden_states list)");
+    if ((dist || mr) && fo.selection != S3ENC_SEL_HIDDEN)
+        return fail("s3enc_forward: DistilHuBERT / multires-HuBERT have one selection (their hidden_states list)");
+    if (mr && fo.featurize)
+        return fail("s3enc_forward: the featurize epilogue is not built for multires-HuBERT (take the states and s3enc_weighted_sum)");
     const int NS = num_states(c, fo.selection);
     if (fo.featurize && !fo.w) return fail("s3enc_forward: featurize needs feat_w");
     if (!fo.featurize && fo.out_dtype != F32 && (fo.out_dtype != dt || dt == F32))
@@ -781,8 +1378,12 @@ int forward_impl(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
     if (T < 1) return fail("s3enc_forward: input shorter than the receptive field of the conv stack");
     const long M = (long)B * T;
     if (!out) return fail("s3enc_forward: null output");
+    MrPlan plan;  // multires-HuBERT: the frame geometry of the U-net; the states are (B, plan.T_out, D)
+    if (mr) mr_plan(c, T, plan);
+    for (const auto& bp : plan.blocks)
+        if (bp.T < 1 || plan.T_out < 1) return fail("s3enc_forward: input too short for the coarsest resolution of the U-net");
     if (!fo.featurize) {
-        if (layer_stride < M * D) return fail("s3enc_forward: layer_stride < B*T*D");
+        if (layer_stride < (mr ? (long)B * plan.T_out : M) * D) return fail("s3enc_forward: layer_stride < B*T*D");
         if (layer_stride & 3) return fail("s3enc_forward: layer_stride must be a multiple of 4 elements (vector stores)");
     }
     if ((uintptr_t)out & 15) return fail("s3enc_forward: out must be 16-byte aligned");
@@ -792,11 +1393,28 @@ int forward_impl(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
         valid[b] = valid_frames(c, lengths[b], n_max);
         if (valid[b] < 1) return fail("s3enc_forward: an utterance is too short to produce a valid frame");
     }
+    // multires-HuBERT: un-masked frames per block — the padding mask follows every adapter as
+    // repeat_interleave(up)[::down][:T'] (hubert_model.py:1080-1084,1169-1172,1256-1258) and align_size_sum's cut (:777-783)
+    std::vector<int> valid_blk;  // blocks 1.., B entries each (block 0 uses `valid`)
+    if (mr) {
+        std::vector<int> v = valid;
+        for (size_t bi = 1; bi < plan.blocks.size(); ++bi) {
+            const MrBlockPlan& bp = plan.blocks[bi];
+            const AdapterW& aw = e->mr_adapters[bp.adapter];
+            const long up = aw.kind == 1 ? 1 : aw.up_rate, down = aw.kind == 2 ? 1 : aw.down_rate;
+            for (int b = 0; b < B; ++b) {
+                long nv = ((long)v[b] * up + down - 1) / down;
+                v[b] = (int)std::min(nv, bp.T);
+            }
+            valid_blk.insert(valid_blk.end(), v.begin(), v.end());
+            for (int b = 0; b < B; ++b) v[b] = (int)std::min<long>(v[b], bp.T_sum);
+        }
+    }
     DeviceGuard dg(e->device);
     if (!dg.ok) return fail("s3enc_forward: hipSetDevice failed");
 
     // ---- small device state: tables + stats ----
-    const size_t tbl_bytes = (size_t)B * (8 + 8 + 4);
+    const size_t tbl_bytes = (size_t)B * (8 + 8 + 4) + valid_blk.size() * 4;
     const size_t part_elems = stats_partial_elems(B, n_max);
     {
         Bump sb(nullptr);
@@ -831,6 +1449,7 @@ int forward_impl(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
         memcpy(hp, wav_ptrs_host, (size_t)B * 8);
         for (int b = 0; b < B; ++b) ((long*)(hp + (size_t)B * 8))[b] = (long)lengths[b];
         memcpy(hp + (size_t)B * 16, valid.data(), (size_t)B * 4);
+        if (!valid_blk.empty()) memcpy(hp + (size_t)B * 20, valid_blk.data(), valid_blk.size() * 4);
         HIP_TRY(hipMemcpyAsync(d_tbl, hp, tbl_bytes, hipMemcpyHostToDevice, st));
         HIP_TRY(hipEventRecord(e->slot_ev[slot], st));
     }
@@ -987,6 +1606,11 @@ int forward_impl(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
         e->taps["proj"] = {xproj, M * D, F32};
         HIP_TRY(sink.emit(si_proj, xproj, false));
         HIP_TRY(sink.done(si_proj));
+    }
+    if (mr) {
+        std::vector<const int*> dv(plan.blocks.size(), d_valid);
+        for (size_t bi = 1; bi < plan.blocks.size(); ++bi) dv[bi] = (const int*)(d_tbl + (size_t)B * 20) + (bi - 1) * (size_t)B;
+        return multires_tail(e, st, B, plan, dv, xproj, out, (long)layer_stride, fo.out_dtype);
     }
     // positional conv + residual; hidden_states[0]
     float* x_cur;          // the fp32 residual stream entering the layer loop
@@ -1325,8 +1949,8 @@ int s3enc_forward_ex(s3enc_handle h, const float* const* wavs, const int64_t* le
 int s3enc_num_states(s3enc_handle h, int32_t selection, int32_t* n) {
     if (!h || !n) return fail("s3enc_num_states: null argument");
     if (selection < 0 || selection > 2) return fail("s3enc_num_states: unknown selection");
-    if (h->cfg.family == S3ENC_DISTILLER && selection != S3ENC_SEL_HIDDEN)
-        return fail("s3enc_num_states: DistilHuBERT has one selection (its hidden_states list)");
+    if ((h->cfg.family == S3ENC_DISTILLER || h->cfg.family == S3ENC_MULTIRES) && selection != S3ENC_SEL_HIDDEN)
+        return fail("s3enc_num_states: DistilHuBERT / multires-HuBERT have one selection (their hidden_states list)");
     *n = num_states(h->cfg, selection);
     return 0;
 }
@@ -1349,7 +1973,7 @@ int s3enc_set_layer_events(s3enc_handle h, void* const* events, int32_t n) {
         h->layer_events.clear();
         return 0;
     }
-    if (!events || n < h->cfg.encoder_layers || n > h->cfg.encoder_layers + 1 + h->cfg.pred_heads)
+    if (!events || n < h->cfg.encoder_layers || n > num_states(h->cfg, S3ENC_SEL_HIDDEN))
         return fail("s3enc_set_layer_events: pass one event per state of the selection the forwards will use");
     h->layer_events.assign((hipEvent_t const*)events, (hipEvent_t const*)events + n);
     return 0;

@@ -142,6 +142,51 @@ hipError_t launch_posconv(const PosConvParams& p, hipStream_t s);
 // 16-bit operand modes: p.w = 16-bit pack [G][Dg][K*Dg] with k = tap*Dg + ci; x / out / bias fp32
 hipError_t launch_posconv16(int dtype, const PosConvParams& p, hipStream_t s);
 
+// ---- adapter.hip (multires-HuBERT: the row passes of the conv adapters, multires_hubert/hubert_model.py:970-1266) ------
+// Operand geometry of the adapter convolutions: per utterance `total` rows of D — `lead` zero rows, the data rows, zero
+// rows to the end — so that a Conv1d / ConvTranspose1d window that hangs over either end reads zeros and the convolution
+// is a plain GEMM over contiguous k*D-element rows (engine.hip).
+struct PadCopyParams {
+    const float* a;      // (B, >= rows, D) fp32, utterance b at a + b*a_bs
+    long a_bs;
+    const float* b;      // optional second term added row by row (x + residual, align_size_sum), or null
+    long b_bs;
+    int B, rows, D;      // data rows copied per utterance
+    int lead, total;     // output rows: [0, lead) zero, [lead, lead + rows) data, [lead + rows, total) zero
+    const int* zero_from;  // optional [B]: data rows >= zero_from[b] are written as zero
+    float* out32;        // (B, total, D) fp32 and / or ...
+    void* out16;         // ... the 16-bit compute dtype; either may be null
+};
+hipError_t launch_pad_copy(int dtype, const PadCopyParams& p, hipStream_t s);
+constexpr int GS_BLOCKS = 64;  // partial sums per utterance of the one-group GroupNorm statistics
+// partial[b][blk] = {sum, sum of squares} over slice blk of the `count` contiguous fp32 values at x + b*bs
+hipError_t launch_group1_stats(const float* x, long bs, long count, int B, double* partial /*[B][GS_BLOCKS][2]*/, hipStream_t s);
+struct AdapterApplyParams {
+    const float* conv;      // (B, L, D) fp32 conv output, utterance b at conv + b*conv_bs
+    long conv_bs;
+    const double* partial;  // launch_group1_stats of that output
+    double count;           // elements per utterance the statistics run over (L * D: ALL conv frames, kept or not)
+    const float* gamma;     // GroupNorm(1, D) affine
+    const float* beta;
+    const float* r1;        // skip term: row (t * r1_mul) / r1_div of utterance b at r1 + b*r1_bs
+    long r1_bs;
+    int r1_mul, r1_div;
+    const float* r2;        // highway term (ConvAdapter) or null
+    long r2_bs;
+    int r2_mul, r2_div;
+    float scale;            // sqrt(residual_scale)
+    int B, rows, D;         // kept output frames per utterance
+    int lead, total;        // output geometry as in PadCopyParams (lead = 0, total = rows: a plain (B, rows, D) tensor)
+    const int* zero_from;   // optional [B]: frames >= zero_from[b] are written as zero (the next encoder's index_put)
+    float* out32;
+    void* out16;
+    int fast_gelu;          // fp32 instantiation only: the 1.5e-7 erf (S3ENC_F32X3); the 16-bit ones always use it
+};
+hipError_t launch_adapter_apply(int dtype, const AdapterApplyParams& p, hipStream_t s);
+// state of a block -> (B, rows_out, D) slot: out[b][t] = x[b][t / factor]  (repeat_interleave + cut, expert.py:26-27,93-101)
+hipError_t launch_emit_upsampled(int dtype, const float* x, long x_bs, int factor, int B, int rows_out, int D, float* out32,
+                                 void* out16, hipStream_t s);
+
 // ---- featurizer.hip (weighted sum over layers, the consumer of hidden_states) ---------------------
 #define S3_WS_MAX_LAYERS 32
 // out[row] = sum_l w[l] * (normalize ? layer_norm(hs[l][row]) : hs[l][row]);  w: HOST array (softmax already applied,

@@ -64,6 +64,13 @@ class HipEncoder:
         _lib.check(self._lib.s3enc_num_frames(self._h, int(n), C.byref(t)))
         return t.value
 
+    def num_output_frames(self, n: int) -> int:
+        """Frames of the states a forward writes for a batch padded to ``n`` samples (``num_frames`` except for
+        multires-HuBERT, whose states are cut to the common length of its resolutions)."""
+        t = C.c_int32()
+        _lib.check(self._lib.s3enc_num_output_frames(self._h, int(n), C.byref(t)))
+        return t.value
+
     def valid_frames(self, length: int, n_max: int) -> int:
         v = C.c_int32()
         _lib.check(self._lib.s3enc_valid_frames(self._h, int(length), int(n_max), C.byref(v)))
@@ -97,9 +104,11 @@ class HipEncoder:
             held.append(w)
         lengths = [int(w.numel()) for w in held]
         nm = max(lengths) if n_max is None else int(n_max)
-        T = self.num_frames(nm)
-        if T < 1:
+        if self.num_frames(nm) < 1:
             raise ValueError(f"input of {nm} samples is shorter than the receptive field of the conv stack")
+        T = self.num_output_frames(nm)
+        if T < 1:
+            raise ValueError(f"input of {nm} samples is too short for the coarsest resolution of the model")
         return dev, held, lengths, nm, T
 
     def forward(self, wavs: Sequence["torch.Tensor"], n_max: Optional[int] = None, out: Optional["torch.Tensor"] = None,
@@ -148,6 +157,19 @@ class HipEncoder:
         w = [float(x) for x in weights]
         if len(w) != NS:
             raise ValueError(f"need one weight per state ({NS}), got {len(w)}")
+        if self.cfg.family == "multires_hubert":
+            # the U-net's states live at different frame rates inside the library: no fused epilogue — the states are
+            # written once and reduced by the library's weighted-sum kernel (s3enc_weighted_sum), still on the GPU
+            hs = self.forward(held, n_max=nm)
+            if out is None:
+                out = torch.empty((B, T, D), dtype=torch.float32, device=dev)
+            wp = (C.c_float * NS)(*w)
+            with torch.cuda.device(dev):
+                stream = torch.cuda.current_stream(dev).cuda_stream
+                rc = self._lib.s3enc_weighted_sum(C.c_void_p(hs.data_ptr()), B * T * D, NS, wp, int(bool(normalize)), B * T, D,
+                                                  C.c_void_p(out.data_ptr()), C.c_void_p(stream))
+            _lib.check(rc, "s3enc_weighted_sum")
+            return out
         if out is None:
             out = torch.empty((B, T, D), dtype=torch.float32, device=dev)
         else:

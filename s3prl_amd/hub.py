@@ -9,6 +9,7 @@ from .upstream.wavlm.hubconf import *  # noqa: F401,F403
 from .upstream.unispeech_sat.hubconf import *  # noqa: F401,F403
 from .upstream.distiller.hubconf import *  # noqa: F401,F403
 from .upstream.data2vec.hubconf import *  # noqa: F401,F403
+from .upstream.multires_hubert.hubconf import *  # noqa: F401,F403
 from .upstream.hf_hubert.hubconf import *  # noqa: F401,F403
 from .upstream.hf_wav2vec2.hubconf import *  # noqa: F401,F403
 from .upstream.baseline.hubconf import *  # noqa: F401,F403

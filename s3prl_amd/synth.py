@@ -40,6 +40,8 @@ def param_shapes(cfg: EncoderConfig) -> Dict[str, tuple]:
         s["layer_norm.bias"] = (C,)
     s["post_extract_proj.weight"] = (D, C)
     s["post_extract_proj.bias"] = (D,)
+    if cfg.family == "multires_hubert":
+        return _multires_shapes(cfg, s)
     if cfg.pos_conv_depth > 1:  # data2vec: plain convs, no weight_norm (wav2vec2_model.py:3001-3007)
         for i in range(cfg.pos_conv_depth):
             s[f"encoder.pos_conv.{i}.0.weight"] = (D, D // cfg.conv_pos_groups, cfg.pos_conv_kernel)
@@ -52,17 +54,7 @@ def param_shapes(cfg: EncoderConfig) -> Dict[str, tuple]:
     s["encoder.layer_norm.bias"] = (D,)
     for l in range(cfg.encoder_layers):
         p = f"encoder.layers.{l}"
-        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
-            s[f"{p}.self_attn.{n}.weight"] = (D, D)
-            s[f"{p}.self_attn.{n}.bias"] = (D,)
-        s[f"{p}.self_attn_layer_norm.weight"] = (D,)
-        s[f"{p}.self_attn_layer_norm.bias"] = (D,)
-        s[f"{p}.fc1.weight"] = (F, D)
-        s[f"{p}.fc1.bias"] = (F,)
-        s[f"{p}.fc2.weight"] = (D, F)
-        s[f"{p}.fc2.bias"] = (D,)
-        s[f"{p}.final_layer_norm.weight"] = (D,)
-        s[f"{p}.final_layer_norm.bias"] = (D,)
+        _layer_shapes(s, p, D, F)
         if cfg.family == "wavlm":
             if cfg.relative_position_embedding and l == 0:
                 s[f"{p}.self_attn.relative_attention_bias.weight"] = (cfg.num_buckets, H)
@@ -79,6 +71,47 @@ def param_shapes(cfg: EncoderConfig) -> Dict[str, tuple]:
     return s
 
 
+def _layer_shapes(s: Dict[str, tuple], p: str, D: int, F: int) -> None:
+    for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+        s[f"{p}.self_attn.{n}.weight"] = (D, D)
+        s[f"{p}.self_attn.{n}.bias"] = (D,)
+    s[f"{p}.self_attn_layer_norm.weight"] = (D,)
+    s[f"{p}.self_attn_layer_norm.bias"] = (D,)
+    s[f"{p}.fc1.weight"] = (F, D)
+    s[f"{p}.fc1.bias"] = (F,)
+    s[f"{p}.fc2.weight"] = (D, F)
+    s[f"{p}.fc2.bias"] = (D,)
+    s[f"{p}.final_layer_norm.weight"] = (D,)
+    s[f"{p}.final_layer_norm.bias"] = (D,)
+
+
+def _multires_shapes(cfg: EncoderConfig, s: Dict[str, tuple]) -> Dict[str, tuple]:
+    """multires-HuBERT (hubert_model.py:337-530): encoders.{i} / middle_encoder / decoders.{i} TransformerEncoders (only
+    encoders.0 keeps its positional conv, :399-403,434-449) and the conv adapters between them."""
+    D, F, k = cfg.encoder_embed_dim, cfg.encoder_ffn_embed_dim, cfg.conv_adapter_kernel
+    R = len(cfg.rate_pairs) + 1
+    names = [f"encoders.{i}" for i in range(R - 1)] + ["middle_encoder"] + [f"decoders.{i}" for i in range(R - 1)]
+    for bi, name in enumerate(names):
+        if bi == 0:
+            s[f"{name}.pos_conv.0.bias"] = (D,)
+            s[f"{name}.pos_conv.0.weight_g"] = (1, 1, cfg.conv_pos)
+            s[f"{name}.pos_conv.0.weight_v"] = (D, D // cfg.conv_pos_groups, cfg.conv_pos)
+        s[f"{name}.layer_norm.weight"] = (D,)
+        s[f"{name}.layer_norm.bias"] = (D,)
+        for l in range(cfg.block_layers[bi]):
+            _layer_shapes(s, f"{name}.layers.{l}", D, F)
+    for i in range(R - 1):
+        for mod, convs in ((f"downsample_modules.{i}", ("downsample_conv",) if cfg.use_plain_updownsample
+                            else ("upsample_conv", "downsample_conv")),
+                           (f"upsample_modules.{i}", ("upsample_conv",) if cfg.use_plain_updownsample
+                            else ("upsample_conv", "downsample_conv"))):
+            for cv in convs:
+                s[f"{mod}.{cv}.0.weight"] = (D, D, k)  # Conv1d (out, in, k) / ConvTranspose1d (in, out, k)
+                s[f"{mod}.{cv}.2.weight"] = (D,)       # Fp32GroupNorm(1, D)
+                s[f"{mod}.{cv}.2.bias"] = (D,)
+    return s
+
+
 def synth_weights(cfg: EncoderConfig, seed: int = 0) -> Dict[str, np.ndarray]:
     """Seeded fp32 weights for every hot-path parameter."""
     rng = np.random.default_rng(seed)
@@ -91,7 +124,7 @@ def synth_weights(cfg: EncoderConfig, seed: int = 0) -> Dict[str, np.ndarray]:
             w = 1.0 + 0.3 * rng.standard_normal(shape)
         elif name.endswith("weight_g"):
             # weight_norm gain: w[:,:,k] = g[k] * v[:,:,k] / ||v[:,:,k]||  → RMS(w) = g/sqrt(numel per tap)
-            d_out, d_in, _ = param_shapes(cfg)["encoder.pos_conv.0.weight_v"]
+            d_out, d_in, _ = param_shapes(cfg)[name[:-1] + "v"]
             w = (1.0 + 0.2 * rng.standard_normal(shape)) * np.sqrt(d_out / shape[-1]) * 0.5
         elif name == "output_layer.2.weight":  # SplitLinear (N, Din, Dout)
             w = rng.standard_normal(shape) * np.sqrt(1.0 / shape[1])
@@ -101,6 +134,8 @@ def synth_weights(cfg: EncoderConfig, seed: int = 0) -> Dict[str, np.ndarray]:
             w = 0.05 * rng.standard_normal(shape)
         elif "pos_conv" in name and leaf == "weight":  # data2vec conv block (out, in/g, k)
             w = rng.standard_normal(shape) * np.sqrt(2.0 / (shape[1] * shape[2]))
+        elif "sample_conv.0" in name:  # conv adapters (D, D, k): unit-variance output before the GroupNorm
+            w = rng.standard_normal(shape) * np.sqrt(1.0 / (shape[1] * shape[2]))
         elif "conv_layers" in name:  # (out, in, k): keep unit variance through GELU (gain ~ sqrt(2.5))
             fan_in = shape[1] * shape[2]
             w = rng.standard_normal(shape) * np.sqrt(2.5 / fan_in)
@@ -162,6 +197,18 @@ def named_config(name: str) -> EncoderConfig:
         "tiny_data2vec": dict(family="wav2vec2", **{**tiny, "extractor_mode": "layer_norm", "conv_pos": 15,
                                                    "pos_conv_depth": 3, "normalize": True}),
         "tiny_hubert": dict(family="hubert", **tiny),
+        # multires-HuBERT (mrhubert_mono_base: 20 ms -> 40 ms -> 20 ms, 4 layers each; the hyper-parameters are those of
+        # the released checkpoint's config as far as the reference tree shows them: hubert_model.py:97-330 defaults)
+        "multires_hubert_base": dict(family="multires_hubert", label_rate_ratios=[1, 2], block_layers=[4, 4, 4]),
+        "tiny_multires": dict(family="multires_hubert", label_rate_ratios=[1, 2], block_layers=[2, 1, 2],
+                              **{**tiny, "encoder_layers": 5}),
+        "tiny_multires_large": dict(family="multires_hubert", label_rate_ratios=[1, 2], block_layers=[1, 2, 1],
+                                    **{**tiny, "encoder_layers": 4, "extractor_mode": "layer_norm",
+                                       "layer_norm_first": True, "normalize": True}),
+        "tiny_multires3": dict(family="multires_hubert", label_rate_ratios=[1, 2, 1, 2], block_layers=[1, 1, 2, 1, 1],
+                               **{**tiny, "encoder_layers": 6}),
+        "tiny_multires_plain": dict(family="multires_hubert", label_rate_ratios=[1, 2], block_layers=[1, 1, 1],
+                                    use_plain_updownsample=True, **{**tiny, "encoder_layers": 3}),
         "tiny_wav2vec2": dict(family="wav2vec2", **tiny),
         "tiny_hubert_large": dict(family="hubert", **{**tiny, "extractor_mode": "layer_norm",
                                                       "layer_norm_first": True, "normalize": True,

@@ -61,6 +61,14 @@ CASES = {
     "distilhubert_pseudo": ("distilhubert", 0, 31, [23456, 16000], (4, 8), 0.0, 1.0),
     "tiny_data2vec_pad": ("tiny_data2vec", 12, 32, [4000, 2345, 3111], (1, 1), 0.0, 1.0),
     "data2vec_base_pseudo": ("data2vec_base", 0, 33, [23456, 16000], (4, 8), 0.0, 1.0),
+    # multi-resolution HuBERT (upstream/multires_hubert): ConvAdapter U-net, post-LN and pre-LN, three resolutions, the plain
+    # ConvDownsampler / ConvUpsampler variant, an odd and an even frame count, and the base shape (20 ms -> 40 ms -> 20 ms)
+    "tiny_multires_pad": ("tiny_multires", 13, 34, [4000, 2345, 3111, 800], (1, 1), 0.0, 1.0),
+    "tiny_multires_eq": ("tiny_multires", 14, 35, [3300, 3300], (1, 1), 0.1, 0.5),
+    "tiny_multires_large_pad": ("tiny_multires_large", 15, 36, [4000, 2345, 3111], (1, 1), 0.3, 2.0),
+    "tiny_multires3_pad": ("tiny_multires3", 16, 37, [4000, 2345, 3111, 1500], (1, 1), 0.0, 1.0),
+    "tiny_multires_plain_pad": ("tiny_multires_plain", 17, 38, [3500, 4000, 1700], (1, 1), 0.0, 1.0),
+    "multires_hubert_base_pseudo": ("multires_hubert_base", 0, 39, [23456, 16000], (4, 8), 0.0, 1.0),
     # wav2vec2 feature_selection (wav2vec2/expert.py:81-93)
     "tiny_wav2vec2_fslayers": ("tiny_wav2vec2", 3, 13, [4000, 2345, 3111, 800], (1, 1), 0.0, 1.0,
                                {"selection": "fairseq_layers"}),
@@ -109,6 +117,27 @@ def build_reference_expert(cfg, weights, tmpdir, extras=None):
         _load(model, weights)
         torch.save({"task_cfg": dataclasses.asdict(tc), "model_cfg": dataclasses.asdict(mc),
                     "model_weight": model.state_dict(), "dictionaries_symbols": [["a"] * 8]}, path)
+    elif cfg.family == "multires_hubert":
+        from s3prl.upstream.multires_hubert.expert import UpstreamExpert
+        from s3prl.upstream.multires_hubert.hubert_model import (MultiresHubertConfig, MultiresHubertModel,
+                                                                  MultiresHubertPretrainingConfig)
+
+        R = len(cfg.rate_pairs) + 1
+        bl = cfg.block_layers
+        override = bl[:R] + [bl[2 * R - 2 - i] for i in range(R - 1)]  # encoders, middle, then decoders reversed (:415-424)
+        mc = MultiresHubertConfig(label_rate=50.0, label_rate_ratios=list(cfg.label_rate_ratios), final_dim=32,
+                                  override_encoder_layers=str(override), conv_adapator_kernal=cfg.conv_adapter_kernel,
+                                  use_plain_updownsample=cfg.use_plain_updownsample, untie_final_proj=False,
+                                  **{**common, "encoder_layers": bl[0]})
+        tc = MultiresHubertPretrainingConfig(label_rate=50.0, label_rate_ratios=list(cfg.label_rate_ratios), sample_rate=16000,
+                                             normalize=cfg.normalize, enable_padding=False, max_keep_size=None,
+                                             max_sample_size=None, min_sample_size=None, single_target=False,
+                                             random_crop=True, pad_audio=False)
+        symbols = [["a"] * 8] * R
+        model = MultiresHubertModel(mc, tc, symbols)
+        _load(model, weights)
+        torch.save({"task_cfg": dataclasses.asdict(tc), "model_cfg": dataclasses.asdict(mc),
+                    "model_weight": model.state_dict(), "dictionaries_symbols": symbols}, path)
     elif cfg.family == "wav2vec2" and cfg.pos_conv_depth > 1:  # data2vec-audio (upstream/data2vec)
         from s3prl.upstream.data2vec.data2vec_model import Data2VecAudioConfig, Data2VecAudioModel
         from s3prl.upstream.data2vec.expert import UpstreamExpert

@@ -92,7 +92,8 @@ FULL_SIZE = ["hubert_large_10s", "wavlm_large_15s_pad"]
 @pytest.mark.parametrize("dtype,tol", [("bf16", 3e-2), ("fp16", 4e-3)])
 @pytest.mark.parametrize("name", ["tiny_hubert_pad", "tiny_wavlm_large_pad", "hubert_base_pseudo", "hubert_large_pseudo",
                                   "tiny_distiller_pad", "tiny_wav2vec2_large_fsbefore", "tiny_data2vec_pad",
-                                  "data2vec_base_pseudo"] + FULL_SIZE)
+                                  "data2vec_base_pseudo", "tiny_multires_pad", "tiny_multires_large_pad", "tiny_multires3_pad",
+                                  "multires_hubert_base_pseudo"] + FULL_SIZE)
 def test_16bit_paths_close_to_reference(name, dtype, tol, golden_loader):
     meta, cfg, weights, wavs, golden, _ = golden_loader(name)
     enc = _encoder(cfg, weights, dtype=dtype)
@@ -345,7 +346,8 @@ def test_extract_feat_tool_dumps_reference_layouts(tmp_path):
 
 @pytest.mark.parametrize("name", ["tiny_hubert_pad", "tiny_wavlm_large_pad", "hubert_base_pseudo", "hubert_large_pseudo",
                                   "tiny_distiller_pad", "distilhubert_pseudo", "tiny_wav2vec2_large_fslayers", "tiny_data2vec_pad",
-                                  "data2vec_base_pseudo"] + FULL_SIZE)
+                                  "data2vec_base_pseudo", "tiny_multires_pad", "tiny_multires_large_pad", "tiny_multires_plain_pad",
+                                  "multires_hubert_base_pseudo"] + FULL_SIZE)
 def test_fp32x3_split_precision_mode_close_to_reference(name, golden_loader):
     """compute_dtype S3ENC_F32X3 (fp32 data flow, GEMMs as three bf16 MFMAs per product): two orders tighter than the
     1e-3 target, one order looser than the exact fp32 mode."""
