@@ -78,6 +78,26 @@ def flops_per_utt(cfg, n):
     T = L[-1]
     Tp = T + (T % 2) if cfg.family in ("hubert", "wav2vec2") else T
     f += 2.0 * T * C * D + 2.0 * T * D * (D // cfg.conv_pos_groups) * cfg.conv_pos
+    if cfg.family == "multires_hubert":
+        # the same per-layer formula at every block's own frame count, plus the adapter convolutions as the reference
+        # runs them (ConvTranspose1d: 2*D*D*k per INPUT frame, Conv1d: 2*D*D*k per OUTPUT frame; hubert_model.py:970-1266)
+        k = cfg.conv_adapter_kernel
+        for blk in cfg.multires_plan(T)[0]:
+            tb = blk["T"] + (blk["T"] % 2)
+            f += blk["layers"] * (2.0 * tb * (4 * D * D + 2 * D * F) + 4.0 * tb * tb * D)
+        prev = None
+        for blk in cfg.multires_plan(T)[0]:
+            if blk["adapter"] is not None:
+                kind, up, down, _ = blk["adapter"]
+                t_in = prev["T"] if "T_sum" not in prev else prev["T_sum"]
+                rows = t_in
+                if kind in ("full", "up"):
+                    f += 2.0 * rows * D * D * k
+                    rows *= up
+                if kind in ("full", "down"):
+                    f += 2.0 * ((rows - 1) // down + 1) * D * D * k
+            prev = blk
+        return f
     f += NL * (2.0 * Tp * (4 * D * D + 2 * D * F) + 4.0 * Tp * Tp * D)
     return f
 
@@ -229,7 +249,7 @@ def main():
         rng = np.random.default_rng(1234 + rank)
         lens = [n] + [int(x) for x in rng.integers(16000, n, size=B - 1)]
     wavs = [torch.randn(m, device=dev, generator=gen) for m in lens]
-    T = enc.num_frames(n)
+    T = enc.num_output_frames(n)  # = num_frames(n) except for multires-HuBERT (states cut to their common length)
     frames_per_batch = sum(enc.num_frames(m) for m in lens)
     NL, D = cfg.encoder_layers, cfg.encoder_embed_dim
     NS = enc.num_states()
@@ -368,7 +388,7 @@ def main():
             "path_tflops": round(world * B * flops_per_utt(cfg, n) / (ms_per_step * 1e-3) / 1e12, 2),
             "roofline": {
                 "kernel": ({"fp32": "gemm_kernel<float> (gemm.hip)", "fp32x3": "gemm_x3_kernel (gemm_x3.hip)"}.get(args.dtype, "gemm16_big_kernel (gemm16.hip)"))
-                          + ": conv1-6 implicit GEMM + proj/qkv/out_proj/fc1/fc2",
+                          + ": conv1-6 implicit GEMM + proj/qkv/out_proj/fc1/fc2 (+ heads / adapter convolutions where the model has them)",
                 "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4), "traffic": None, "algorithmic_bytes": round(g_by / max(g_n, 1)),
                 "launches_per_step": g_n // max(prof_steps, 1), "avg_launch_ms": round(g_ms / max(g_n, 1), 4),

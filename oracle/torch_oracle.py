@@ -30,9 +30,10 @@ def prepare(cfg, weights: Dict[str, np.ndarray], dtype=torch.float32) -> Dict[st
     """state_dict -> torch tensors; folds ``weight_norm(dim=2)`` of the positional conv
     (wav2vec2_model.py:2950; WavLM.py:548) once, like the parametrisation does on every forward."""
     W = {k: _t(weights, k, dtype) for k in weights}
-    if "encoder.pos_conv.0.weight_g" in W:
-        g, v = W["encoder.pos_conv.0.weight_g"].double(), W["encoder.pos_conv.0.weight_v"].double()
-        W["encoder.pos_conv.0.weight"] = (g * v / v.pow(2).sum(dim=(0, 1), keepdim=True).sqrt()).to(dtype)
+    for enc in ("encoder", "encoders.0"):  # "encoders.0": multires-HuBERT's only positional conv
+        if f"{enc}.pos_conv.0.weight_g" in W:
+            g, v = W[f"{enc}.pos_conv.0.weight_g"].double(), W[f"{enc}.pos_conv.0.weight_v"].double()
+            W[f"{enc}.pos_conv.0.weight"] = (g * v / v.pow(2).sum(dim=(0, 1), keepdim=True).sqrt()).to(dtype)
     return W
 
 
@@ -97,9 +98,9 @@ def self_attention(cfg, W, p: str, x_tbc: torch.Tensor, key_padding_mask: Option
     return out
 
 
-def encoder_layer(cfg, W, l: int, x: torch.Tensor, kpm, pos_bias) -> torch.Tensor:
+def encoder_layer(cfg, W, l: int, x: torch.Tensor, kpm, pos_bias, prefix: str = "encoder") -> torch.Tensor:
     """``TransformerSentenceEncoderLayer.forward`` (wav2vec2_model.py:3260-3322; WavLM.py:709-774), (T,B,C)."""
-    p = f"encoder.layers.{l}"
+    p = f"{prefix}.layers.{l}"
     D = x.shape[-1]
     ln1 = (W[f"{p}.self_attn_layer_norm.weight"], W[f"{p}.self_attn_layer_norm.bias"])
     ln2 = (W[f"{p}.final_layer_norm.weight"], W[f"{p}.final_layer_norm.bias"])
@@ -121,6 +122,8 @@ def encoder_layer(cfg, W, l: int, x: torch.Tensor, kpm, pos_bias) -> torch.Tenso
 def forward(cfg, W: Dict[str, torch.Tensor], wavs: List[torch.Tensor], n_max: Optional[int] = None) -> List[torch.Tensor]:
     """``UpstreamExpert.__call__(wavs)["hidden_states"]`` (hubert/expert.py:56-72 -> hubert_model.py:466-513 ->
     wav2vec2_model.py:3046-3121 with the hook capture of upstream/interfaces.py:90-131).  ``W = prepare(...)``."""
+    if cfg.family == "multires_hubert":
+        return multires_forward(cfg, W, wavs, n_max)
     dt = W["layer_norm.weight"].dtype
     lens = [int(w.numel()) for w in wavs]
     n_max = n_max or max(lens)
@@ -169,3 +172,100 @@ def forward(cfg, W: Dict[str, torch.Tensor], wavs: List[torch.Tensor], n_max: Op
         x = F.layer_norm(x, (x.shape[-1],), W["encoder.layer_norm.weight"], W["encoder.layer_norm.bias"], 1e-5)
     hidden.append(x)
     return hidden
+
+
+# ---- multi-resolution HuBERT (upstream/multires_hubert) -----------------------------------------------------------------
+
+def conv_adapter(W, mod: str, x_bct: torch.Tensor, up: int, down: int, kind: str) -> torch.Tensor:
+    """``ConvAdapter`` / ``ConvDownsampler`` / ``ConvUpsampler`` forward (multires_hubert/hubert_model.py:1038-1078,
+    1146-1167,1232-1250) on (B, C, T): ConvTranspose1d / Conv1d -> Fp32GroupNorm(1, C) -> GELU, skip connections scaled
+    by sqrt(0.4), the highway branch for the two-conv adapter."""
+    sc = 0.4 ** 0.5
+    C = x_bct.shape[1]
+    r_up = None
+    x = x_bct
+    if kind in ("full", "up"):
+        p = f"{mod}.upsample_conv"
+        y = F.conv_transpose1d(x, W[f"{p}.0.weight"], None, stride=up, padding=0, output_padding=up - 1)
+        y = F.gelu(F.group_norm(y.float(), 1, W[f"{p}.2.weight"], W[f"{p}.2.bias"], 1e-5).type_as(y))
+        r_up = torch.repeat_interleave(x, up, dim=2)
+        n = min(y.shape[2], r_up.shape[2])
+        x = (y[..., :n] + r_up[..., :n]) * sc
+    if kind in ("full", "down"):
+        p = f"{mod}.downsample_conv"
+        k = W[f"{p}.0.weight"].shape[-1]
+        y = F.conv1d(x, W[f"{p}.0.weight"], None, stride=down, padding=(k - 1) // 2)
+        y = F.gelu(F.group_norm(y.float(), 1, W[f"{p}.2.weight"], W[f"{p}.2.bias"], 1e-5).type_as(y))
+        r = x[..., ::down]
+        n = min(y.shape[2], r.shape[2])
+        x = (y[..., :n] + r[..., :n]) * sc
+        if kind == "full":
+            r = r_up[..., ::down]
+            n = min(x.shape[2], r.shape[2])
+            x = (x[..., :n] + r[..., :n]) * sc
+    return x
+
+
+@torch.no_grad()
+def multires_forward(cfg, W, wavs: List[torch.Tensor], n_max: Optional[int] = None) -> List[torch.Tensor]:
+    """``UpstreamExpert.__call__(wavs)["hidden_states"]`` of upstream/multires_hubert (expert.py:30-126 ->
+    hubert_model.py:738-852 -> wav2vec2_model.py:3046-3121) on the reference's ATen call sites."""
+    dt = W["layer_norm.weight"].dtype
+    lens = [int(w.numel()) for w in wavs]
+    n_max = n_max or max(lens)
+    B = len(wavs)
+    if cfg.normalize:
+        wavs = [F.layer_norm(w.to(dt), w.shape) for w in wavs]
+    padded = torch.zeros(B, n_max, dtype=dt)
+    for b, w in enumerate(wavs):
+        padded[b, : lens[b]] = w.to(dt)
+    x = feature_extractor(cfg, W, padded).transpose(1, 2)
+    T0 = x.shape[1]
+    x = F.layer_norm(x, (x.shape[-1],), W["layer_norm.weight"], W["layer_norm.bias"], 1e-5)
+    x = F.linear(x, W["post_extract_proj.weight"], W["post_extract_proj.bias"])
+    valid = [cfg.valid_frames(n, n_max) for n in lens]
+    blocks, T_out = cfg.multires_plan(T0)
+    R = len(cfg.rate_pairs) + 1
+    states, residuals = [], []
+    for bi, blk in enumerate(blocks):
+        if blk["adapter"] is not None:
+            kind, up, down, mod = blk["adapter"]
+            x = conv_adapter(W, mod, x.transpose(1, 2), up, down, kind).transpose(1, 2)
+            ue, de = (up if kind != "down" else 1), (down if kind != "up" else 1)
+            valid = [min(-(-(v * ue) // de), x.shape[1]) for v in valid]
+        T = x.shape[1]
+        kpm = torch.zeros(B, T, dtype=torch.bool)
+        for b in range(B):
+            kpm[b, valid[b]:] = True
+        x_in = x.masked_fill(kpm.unsqueeze(-1), 0.0)  # index_put (in place in the reference: visible to x + residual)
+        h = x_in
+        p = blk["prefix"]
+        if bi == 0:
+            K = W[f"{p}.pos_conv.0.weight"].shape[-1]
+            xc = F.conv1d(h.transpose(1, 2), W[f"{p}.pos_conv.0.weight"], W[f"{p}.pos_conv.0.bias"], padding=K // 2,
+                          groups=cfg.conv_pos_groups)
+            if K % 2 == 0:
+                xc = xc[:, :, :-1]
+            h = h + F.gelu(xc).transpose(1, 2)
+        if not cfg.layer_norm_first:
+            h = F.layer_norm(h, (h.shape[-1],), W[f"{p}.layer_norm.weight"], W[f"{p}.layer_norm.bias"], 1e-5)
+        h = h.transpose(0, 1)
+        for l in range(blk["layers"]):
+            states.append((h.transpose(0, 1), blk["factor"]))
+            h = encoder_layer(cfg, W, l, h, kpm, None, prefix=p)
+        h = h.transpose(0, 1)
+        if cfg.layer_norm_first:
+            h = F.layer_norm(h, (h.shape[-1],), W[f"{p}.layer_norm.weight"], W[f"{p}.layer_norm.bias"], 1e-5)
+        states.append((h, blk["factor"]))
+        if bi < R - 1:
+            residuals.append(h)
+            x = h
+        elif bi == R - 1:
+            x = x_in + h
+            residuals.reverse()
+        else:
+            r = residuals[bi - R]
+            c = min(h.shape[1], r.shape[1])
+            x = h[:, :c] + r[:, :c]
+            valid = [min(v, c) for v in valid]
+    return [torch.repeat_interleave(h, f, dim=1)[:, :T_out].contiguous() for h, f in states]

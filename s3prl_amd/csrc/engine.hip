@@ -1216,7 +1216,8 @@ int multires_tail(s3enc_handle e, hipStream_t st, int B, const MrPlan& plan, con
         g.ldo = g.N;
         g.o_bs = *frames * D;
         {
-            Prof pr(e, st, "gemm:adapter", 2.0 * B * Mrows * g.N * g.K,
+            // algorithmic flops: the k real taps (the zero taps that square up the transposed conv's phases are not counted)
+            Prof pr(e, st, "gemm:adapter", 2.0 * B * (transposed ? (double)rows : (double)Mrows) * D * D * k,
                     ((double)B * total * D + (double)g.N * g.K) * es + (double)B * *frames * D * 4);
             HIP_TRY(launch_gemm(dt, g, st));
         }

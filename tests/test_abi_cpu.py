@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     for sym in declared:
         assert hasattr(lib, sym), f"{sym} declared in s3enc.h but not exported by libs3enc.so"
     assert declared == set(_lib._PROTOS), "ctypes prototypes and header disagree"
-    assert lib.s3enc_version() == 2
+    assert lib.s3enc_version() == _lib.ABI_VERSION == 3
 
 
 def test_struct_layout_matches_header(tmp_path):
@@ -44,7 +44,9 @@ def test_struct_layout_matches_header(tmp_path):
         'sizeof(s3enc_profile_entry), offsetof(s3enc_config, compute_dtype), offsetof(s3enc_tensor, shape));'
         'printf("%zu %zu\\n", sizeof(s3enc_fbank_config), offsetof(s3enc_fbank_config, cmvn_eps));'
         'printf("%zu %zu %zu\\n", offsetof(s3enc_config, pred_heads), sizeof(s3enc_forward_opts), '
-        'offsetof(s3enc_forward_opts, feat_w));return 0;}\n'
+        'offsetof(s3enc_forward_opts, feat_w));'
+        'printf("%zu %zu %zu\\n", offsetof(s3enc_config, mr_pairs), offsetof(s3enc_config, mr_layers), '
+        'offsetof(s3enc_config, mr_plain));return 0;}\n'
     )
     exe = tmp_path / "sz"
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)],
@@ -53,7 +55,8 @@ def test_struct_layout_matches_header(tmp_path):
     assert got == [C.sizeof(_lib.S3Config), C.sizeof(_lib.S3Tensor), C.sizeof(_lib.S3ProfileEntry),
                    _lib.S3Config.compute_dtype.offset, _lib.S3Tensor.shape.offset,
                    C.sizeof(_lib.S3FbankConfig), _lib.S3FbankConfig.cmvn_eps.offset,
-                   _lib.S3Config.pred_heads.offset, C.sizeof(_lib.S3ForwardOpts), _lib.S3ForwardOpts.feat_w.offset]
+                   _lib.S3Config.pred_heads.offset, C.sizeof(_lib.S3ForwardOpts), _lib.S3ForwardOpts.feat_w.offset,
+                   _lib.S3Config.mr_pairs.offset, _lib.S3Config.mr_layers.offset, _lib.S3Config.mr_plain.offset]
 
 
 def test_no_gpu_means_loud_failure():

@@ -14,7 +14,8 @@ def test_conv_layer_spec_parser():
         parse_conv_layers("__import__('os').system('true')")
 
 
-@pytest.mark.parametrize("name", ["tiny_hubert", "tiny_wav2vec2_large", "tiny_wavlm_large", "tiny_distiller", "tiny_data2vec"])
+@pytest.mark.parametrize("name", ["tiny_hubert", "tiny_wav2vec2_large", "tiny_wavlm_large", "tiny_distiller", "tiny_data2vec",
+                                  "tiny_multires", "tiny_multires3", "tiny_multires_plain"])
 def test_checkpoint_roundtrip(tmp_path, name):
     from s3prl_amd.ckpt import load_checkpoint, save_checkpoint
     from s3prl_amd.synth import named_config, synth_weights
@@ -46,6 +47,7 @@ def test_hub_entries_follow_the_reference_naming():
     for fam in ("hubert", "wav2vec2", "wavlm", "unispeech_sat", "data2vec"):
         assert fam in names and f"{fam}_local" in names and f"{fam}_custom" in names
     assert "distiller_local" in names and "distilhubert" in names
+    assert "multires_hubert_local" in names and "multires_hubert_base" in names
     assert all(not n.endswith("_local") for n in hub.options(only_registered_ckpt=True))
     for n in ("fbank", "fbank_no_cmvn", "baseline", "baseline_local"):
         assert n in names
@@ -66,3 +68,28 @@ def test_expert_refuses_cpu_tensors(tmp_path):
     assert expert.get_downsample_rates("hidden_states") == 320
     with pytest.raises(RuntimeError, match="MI355X only"):
         expert([torch.zeros(16000)])
+
+
+def test_multires_geometry_and_config_parsing():
+    """The U-net's frame plan (EncoderConfig.multires_plan; the C++ side mirrors it, tests/test_multires_gpu.py) against
+    the shapes the reference expert returned for the golden fixtures, and MultiresHubertConfig's override rule."""
+    from conftest import golden_meta
+    from s3prl_amd.config import config_from_multires
+    from s3prl_amd.synth import named_config
+
+    for name in ("tiny_multires_pad", "tiny_multires_eq", "tiny_multires3_pad", "tiny_multires_plain_pad",
+                 "multires_hubert_base_pseudo"):
+        meta = golden_meta(name)
+        cfg = named_config(meta["config"])
+        assert cfg.num_output_frames(max(meta["lengths"])) == meta["shape"][1]
+        assert cfg.num_hidden_states == meta["n_states"]
+    cfg = named_config("multires_hubert_base")
+    blocks, t_out = cfg.multires_plan(499)
+    assert [(b["T"], b["factor"]) for b in blocks] == [(499, 1), (250, 2), (500, 1)] and t_out == 499
+    # override_encoder_layers = [enc0, enc1, middle, dec(last), dec(first)] (hubert_model.py:415-424)
+    c3 = config_from_multires(dict(label_rate_ratios=[1, 2, 1, 2], override_encoder_layers="[1, 2, 3, 4, 5]"))
+    assert c3.block_layers == [1, 2, 3, 5, 4] and c3.encoder_layers == 15 and c3.num_hidden_states == 20
+    with pytest.raises(ValueError, match="exactly as the Hubert model"):
+        config_from_multires(dict(label_rate_ratios="None"))
+    with pytest.raises(ValueError, match="divide"):
+        config_from_multires(dict(label_rate_ratios=[1, 5]))

@@ -58,8 +58,7 @@ def test_shard_padded_to_global_max_reproduces_full_batch(golden_loader):
 
 def _torch_oracle_cases():
     # the ATen-call-site restatement covers the families bench.py times (no DistilHuBERT heads, no feature_selection)
-    return [n for n in golden_names() if not golden_meta(n).get("selection") and "distil" not in golden_meta(n)["config"]
-            and "multires" not in golden_meta(n)["config"]]
+    return [n for n in golden_names() if not golden_meta(n).get("selection") and "distil" not in golden_meta(n)["config"]]
 
 
 @pytest.mark.parametrize("name", _torch_oracle_cases())
