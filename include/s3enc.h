@@ -157,6 +157,18 @@ int s3enc_num_states(s3enc_handle h, int32_t selection, int32_t* n);
 int s3enc_forward_ex(s3enc_handle h, const float* const* wavs, const int64_t* lengths, int32_t B, int64_t n_max,
                      const s3enc_forward_opts* opts, void* out, int64_t layer_stride, void* stream);
 
+/* hipGraph replay of repeated forwards (off by default).  When on, a forward whose key — (B, n_max, selection, out_dtype,
+ * out, layer_stride) — was already run eagerly once is captured into a hipGraph on its second occurrence and replayed from
+ * the third on: the host then issues one table upload (waveform pointers, lengths, valid frames: the only per-call data
+ * the kernels read) and ONE hipGraphLaunch instead of the ~300-600 kernel launches of a forward.  Meant for latency-bound
+ * serving shapes (a few short utterances, where the GPU finishes a forward faster than the host can enqueue it); it needs
+ * a non-NULL stream and the caller to reuse its output block.  Not used while profiling is enabled, layer events are set,
+ * or with `featurize` (its weights are kernel arguments).  Graphs are discarded when a workspace is re-allocated (a larger
+ * batch shape) and re-captured.  Replaces nothing in the reference (PyTorch eager launches every ATen op per call).
+ * s3enc_graph_stats: graphs captured / forwards replayed so far. */
+int s3enc_set_graph_replay(s3enc_handle h, int32_t on);
+int s3enc_graph_stats(s3enc_handle h, int64_t* captures, int64_t* replays);
+
 /* Optional: `n` = encoder_layers+1 hipEvent_t handles (as void*); the following forwards record events[l] on the
  * launch stream as soon as hidden_states[l] is final, so a communication stream can start the all-gather of layer l
  * while later layers are still computing.  n = 0 clears.  The events stay owned by the caller. */

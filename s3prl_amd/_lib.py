@@ -74,6 +74,8 @@ _PROTOS = {
     "s3enc_num_states": (C.c_int, [_VP, _I32, C.POINTER(_I32)]),
     "s3enc_forward_padded": (C.c_int, [_VP, _VP, _I64, C.POINTER(_I64), _I32, _I64, _VP, _I64, _VP]),
     "s3enc_set_layer_events": (C.c_int, [_VP, C.POINTER(_VP), _I32]),
+    "s3enc_set_graph_replay": (C.c_int, [_VP, _I32]),
+    "s3enc_graph_stats": (C.c_int, [_VP, C.POINTER(_I64), C.POINTER(_I64)]),
     "s3enc_profile_enable": (C.c_int, [_VP, _I32]),
     "s3enc_profile_reset": (C.c_int, [_VP]),
     "s3enc_profile_read": (C.c_int, [_VP, C.POINTER(S3ProfileEntry), _I32, C.POINTER(_I32)]),
