@@ -131,7 +131,74 @@ __global__ __launch_bounds__(256) void emit_up_kernel(const float* x, long x_bs,
     for (int ch = threadIdx.x; ch < (D >> 2); ch += 256) store_row4<T>(out32, out16, off + 4 * ch, *(const float4*)(src + 4 * ch));
 }
 
+// Featurizer term of a block's state at the finest frame rate, without writing the state: acc[b][t] (+)= w * s[b][t / factor]
+// (norm: w * layer_norm(s row), no affine, eps 1e-5) — the arithmetic of emit_kernel / LnAcc in norm.hip.  A wave per row.
+template <int NCH>
+__global__ __launch_bounds__(256) void emit_up_acc_kernel(const float* x, long x_bs, int factor, int rows_out, long rows, int C,
+                                                          LnAcc fa) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const int nch = C >> 2;
+    const long b = row / rows_out;
+    const int t = (int)(row - b * rows_out);
+    const float* xr = x + b * x_bs + (long)(t / factor) * C;
+    float4 v[NCH];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int ch = lane + 64 * i;
+        v[i] = ch < nch ? *(const float4*)(xr + 4 * ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    float a = fa.w, c0 = 0.f;
+    if (fa.norm) {
+        const float invC = 1.f / (float)C;
+        const float mu = wave_sum(s) * invC;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int ch = lane + 64 * i;
+            if (ch < nch) {
+                const float a0 = v[i].x - mu, b0 = v[i].y - mu, c1 = v[i].z - mu, d0 = v[i].w - mu;
+                q += (a0 * a0 + b0 * b0) + (c1 * c1 + d0 * d0);
+            }
+        }
+        a = fa.w * rsqrtf(wave_sum(q) * invC + LN_EPS);
+        c0 = -mu * a;
+    }
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int ch = lane + 64 * i;
+        if (ch >= nch) continue;
+        float4* dst = (float4*)(fa.acc + row * C + 4 * ch);
+        float4 tt = fa.init ? make_float4(0.f, 0.f, 0.f, 0.f) : *dst;
+        tt.x += fmaf(v[i].x, a, c0);
+        tt.y += fmaf(v[i].y, a, c0);
+        tt.z += fmaf(v[i].z, a, c0);
+        tt.w += fmaf(v[i].w, a, c0);
+        *dst = tt;
+    }
+}
+
 }  // namespace
+
+hipError_t launch_emit_upsampled_acc(const float* x, long x_bs, int factor, int B, int rows_out, int D, const LnAcc& fa,
+                                     hipStream_t s) {
+    if (B <= 0 || rows_out <= 0 || !fa.acc) return hipSuccess;
+    if ((D & 3) || D > 2048 || factor < 1) return hipErrorInvalidValue;
+    const long rows = (long)B * rows_out;
+    const int per_lane = ((D >> 2) + 63) / 64;
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+#define S3_EU(N) hipLaunchKernelGGL((emit_up_acc_kernel<N>), grid, block, 0, s, x, x_bs, factor, rows_out, rows, D, fa)
+    if (per_lane <= 1) S3_EU(1);
+    else if (per_lane == 2) S3_EU(2);
+    else if (per_lane == 3) S3_EU(3);
+    else if (per_lane == 4) S3_EU(4);
+    else S3_EU(8);
+#undef S3_EU
+    return hipGetLastError();
+}
 
 hipError_t launch_pad_copy(int dtype, const PadCopyParams& p, hipStream_t s) {
     if (p.B <= 0 || p.total <= 0) return hipSuccess;

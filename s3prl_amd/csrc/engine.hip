@@ -1040,13 +1040,13 @@ struct CaptureGuard {
 // The blocks run the same GEMM / attention / LayerNorm kernels as the single-resolution encoders; the adapter
 // convolutions are GEMMs over zero-bordered frame buffers, their GroupNorm / GELU / skip passes are adapter.hip.
 int multires_tail(s3enc_handle e, hipStream_t st, int B, const MrPlan& plan, const std::vector<const int*>& d_valid, float* xproj,
-                  void* out, long layer_stride, int out_dtype) {
+                  void* out, long layer_stride, const FwdOpts& fo) {
     const s3enc_config& c = e->cfg;
     const int D = c.embed_dim, F = c.ffn_dim, H = c.heads;
     const int dt = e->dtype, es = e->es;
     const bool prel = c.layer_norm_first != 0;
     const int R = c.mr_pairs + 1, NB = 2 * R - 1, k = c.mr_kernel, PADR = k - 1;
-    const bool out16 = out_dtype != F32;
+    const bool out16 = !fo.featurize && fo.out_dtype != F32;
     const float scale = std::sqrt(0.4f);  // sqrt(residual_scale), hubert_model.py:429,1036
 
     // capacities: frames of the widest block, rows of the widest zero-bordered operand, frames of the longest conv output
@@ -1091,8 +1091,24 @@ int multires_tail(s3enc_handle e, hipStream_t st, int B, const MrPlan& plan, con
     }
 
     int si = 0;
-    // a state (B, T, D) -> slot si of the caller's slab at the finest frame rate
+    bool first_term = true;
+    // a state (B, T, D) -> slot si of the caller's slab at the finest frame rate; featurize: only its term of the sum
     auto emit = [&](const float* x, long T, int factor) -> int {
+        if (fo.featurize) {
+            if (fo.w[si] != 0.f) {
+                LnAcc fa;
+                fa.acc = (float*)out;
+                fa.w = fo.w[si];
+                fa.mode = 1;
+                fa.norm = fo.feat_norm;
+                fa.init = first_term;
+                first_term = false;
+                Prof pr(e, st, "emit_state", 0, (double)B * plan.T_out * D * (4.0 / factor + 8));
+                HIP_TRY(launch_emit_upsampled_acc(x, T * D, factor, B, (int)plan.T_out, D, fa, st));
+            }
+            ++si;
+            return 0;
+        }
         float* o32 = out16 ? nullptr : (float*)out + (long)si * layer_stride;
         void* o16 = out16 ? (void*)((u16*)out + (long)si * layer_stride) : nullptr;
         {
@@ -1475,8 +1491,6 @@ int forward_once(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
     if (fo.selection < 0 || fo.selection > 2) return fail("s3enc_forward: unknown selection");
     if ((dist || mr) && fo.selection != S3ENC_SEL_HIDDEN)
         return fail("s3enc_forward: DistilHuBERT / multires-HuBERT have one selection (their hidden_states list)");
-    if (mr && fo.featurize)
-        return fail("s3enc_forward: the featurize epilogue is not built for multires-HuBERT (take the states and s3enc_weighted_sum)");
     const int NS = num_states(c, fo.selection);
     if (fo.featurize && !fo.w) return fail("s3enc_forward: featurize needs feat_w");
     if (!fo.featurize && fo.out_dtype != F32 && (fo.out_dtype != dt || dt == F32))
@@ -1650,7 +1664,7 @@ int forward_once(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
     if (fo.featurize) {
         bool any = false;
         for (int i = 0; i < NS; ++i) any = any || fo.w[i] != 0.f;
-        if (!any) HIP_TRY(hipMemsetAsync(out, 0, (size_t)M * D * 4, st));
+        if (!any) HIP_TRY(hipMemsetAsync(out, 0, (size_t)(mr ? (long)B * plan.T_out : M) * D * 4, st));
     }
     // state index of each tensor of the forward under this selection (-1: not a state)
     const bool hid = fo.selection == S3ENC_SEL_HIDDEN && !dist;
@@ -1773,7 +1787,7 @@ int forward_once(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
     if (mr) {
         std::vector<const int*> dv(plan.blocks.size(), d_valid);
         for (size_t bi = 1; bi < plan.blocks.size(); ++bi) dv[bi] = (const int*)(d_tbl + (size_t)B * 20) + (bi - 1) * (size_t)B;
-        if (multires_tail(e, st, B, plan, dv, xproj, out, (long)layer_stride, fo.out_dtype)) return 1;
+        if (multires_tail(e, st, B, plan, dv, xproj, out, (long)layer_stride, fo)) return 1;
         return cap.finish();
     }
     // positional conv + residual; hidden_states[0]

@@ -187,6 +187,10 @@ hipError_t launch_adapter_apply(int dtype, const AdapterApplyParams& p, hipStrea
 hipError_t launch_emit_upsampled(int dtype, const float* x, long x_bs, int factor, int B, int rows_out, int D, float* out32,
                                  void* out16, hipStream_t s);
 
+// the same state as its Featurizer term only: fa.acc[b][t] (+)= fa.w * (fa.norm ? layer_norm(x[b][t / factor]) : x[b][t / factor])
+hipError_t launch_emit_upsampled_acc(const float* x, long x_bs, int factor, int B, int rows_out, int D, const LnAcc& fa,
+                                     hipStream_t s);
+
 // ---- featurizer.hip (weighted sum over layers, the consumer of hidden_states) ---------------------
 #define S3_WS_MAX_LAYERS 32
 // out[row] = sum_l w[l] * (normalize ? layer_norm(hs[l][row]) : hs[l][row]);  w: HOST array (softmax already applied,

@@ -157,19 +157,6 @@ class HipEncoder:
         w = [float(x) for x in weights]
         if len(w) != NS:
             raise ValueError(f"need one weight per state ({NS}), got {len(w)}")
-        if self.cfg.family == "multires_hubert":
-            # the U-net's states live at different frame rates inside the library: no fused epilogue — the states are
-            # written once and reduced by the library's weighted-sum kernel (s3enc_weighted_sum), still on the GPU
-            hs = self.forward(held, n_max=nm)
-            if out is None:
-                out = torch.empty((B, T, D), dtype=torch.float32, device=dev)
-            wp = (C.c_float * NS)(*w)
-            with torch.cuda.device(dev):
-                stream = torch.cuda.current_stream(dev).cuda_stream
-                rc = self._lib.s3enc_weighted_sum(C.c_void_p(hs.data_ptr()), B * T * D, NS, wp, int(bool(normalize)), B * T, D,
-                                                  C.c_void_p(out.data_ptr()), C.c_void_p(stream))
-            _lib.check(rc, "s3enc_weighted_sum")
-            return out
         if out is None:
             out = torch.empty((B, T, D), dtype=torch.float32, device=dev)
         else:

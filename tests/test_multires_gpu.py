@@ -67,14 +67,18 @@ def test_16bit_states_are_the_rounded_fp32_states(dtype, golden_loader):
     enc.close()
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("name", ["tiny_multires_large_pad", "tiny_multires3_pad"])
 @pytest.mark.parametrize("normalize", [False, True])
-def test_featurized_equals_the_featurizer_oracle(normalize, golden_loader):
+def test_featurized_equals_the_featurizer_oracle(normalize, name, dtype, golden_loader):
+    """The featurize epilogue of the U-net (a state is never written: every block adds w * [layer_norm](state[t / factor])
+    into one (B, T_out, D) block) against the weighted sum of the states the same encoder writes."""
     import torch
 
-    meta, cfg, weights, wavs, golden, _ = golden_loader("tiny_multires_large_pad")
+    meta, cfg, weights, wavs, golden, _ = golden_loader(name)
     from s3prl_amd.encoder import HipEncoder
 
-    enc = HipEncoder(cfg, weights)
+    enc = HipEncoder(cfg, weights, dtype=dtype)
     w = torch.softmax(torch.linspace(-1, 1, cfg.num_hidden_states), 0).tolist()
     w[2] = 0.0
     got = enc.forward_featurized(_dev(wavs), w, normalize=normalize).cpu().numpy()
@@ -83,6 +87,7 @@ def test_featurized_equals_the_featurizer_oracle(normalize, golden_loader):
     for wi, h in zip(w, hs.astype(np.float64)):
         ref += wi * (O.layer_norm(h, None, None) if normalize else h)
     assert O.rel_err(got, ref) < 2e-6
+    assert not enc.forward_featurized(_dev(wavs), [0.0] * cfg.num_hidden_states, normalize=normalize).any()
     with pytest.raises(Exception, match="one selection"):
         enc.forward(_dev(wavs), selection="fairseq_layers")
     enc.close()
@@ -131,4 +136,24 @@ def test_base_shape_matches_torch_free_oracle_on_a_ragged_batch():
     ref = O.forward(cfg, weights, wavs, dtype=np.float32)
     errs = [O.rel_err(hs[l], ref[l]) for l in range(len(ref))]
     assert max(errs) < 1e-4, ["%.2e" % e for e in errs]
+    enc.close()
+
+
+@pytest.mark.parametrize("name", ["tiny_multires", "tiny_multires3", "tiny_multires_large"])
+def test_extra_short_and_odd_lengths_match_the_oracle(name):
+    """EXTRA_SHORT_SEC-style inputs (test/test_upstream.py:24): one or two frames at the finest rate, i.e. ONE frame at
+    the coarsest; and odd / even frame counts on both sides of every adapter."""
+    from s3prl_amd.encoder import HipEncoder
+    from s3prl_amd.synth import named_config, synth_wavs, synth_weights
+
+    cfg = named_config(name)
+    weights = synth_weights(cfg, 21)
+    enc = HipEncoder(cfg, weights)
+    for lengths in ([400], [800, 400], [1039, 720], [1360, 1359], [2000, 1681, 400]):
+        wavs = synth_wavs(lengths, 22)
+        hs = enc.forward(_dev(wavs)).cpu().numpy()
+        ref = O.forward(cfg, weights, wavs, dtype=np.float32)
+        assert hs.shape[2] == ref[0].shape[1] == cfg.num_output_frames(max(lengths))
+        errs = [O.rel_err(hs[l], ref[l]) for l in range(len(ref))]
+        assert max(errs) < 1e-4, (lengths, ["%.2e" % e for e in errs])
     enc.close()

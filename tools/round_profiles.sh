@@ -24,6 +24,10 @@ for g in layers featurized; do
   python bench.py --gpus 2 --backend gloo --gather $g --steps 5 --warmup 1 --no-profile > $out/bench_2rank_gloo_$g.json 2>/dev/null
 done
 python bench.py --gpus 2 --backend gloo --gather layers16 --dtype bf16 --steps 5 --warmup 1 --no-profile > $out/bench_2rank_gloo_layers16.json 2>/dev/null
+for d in fp32 fp32x3 bf16; do
+  python bench.py --model multires_hubert_base --dtype $d --no-cpu-baseline --steps 40 --warmup 3 > $out/bench_multires_hubert_base_$d.json 2>/dev/null
+done
+python tools/graph_latency.py > $out/graph_replay.md 2>/dev/null
 python tools/parity_table.py > $out/parity.md 2> $out/parity.err
 # rocprofv3 kernel trace of the headline command (its own run: never combined with PMC passes)
 rocprofv3 --kernel-trace --stats -d $out/prof_fp32 -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-parity > $out/prof_fp32.log 2>&1
