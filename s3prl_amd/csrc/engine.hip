@@ -1,375 +1,46 @@
-// engine.cpp — the C ABI of libs3enc (include/s3enc.h): handle, weight packer, workspace, forward schedule.
+// engine.hip — the C ABI of libs3enc (include/s3enc.h): handle, weight packer, workspace, forward schedule.
 //
 // Forward schedule (all launches on the caller's stream, no host synchronisation inside):
 //   table upload -> wav stats -> [GroupNorm lag sums] -> conv0 -> conv1..6 (implicit GEMM, GELU fused)
 //   -> LayerNorm(C) -> post_extract_proj (+bias, padded frames zeroed) -> pos-conv (+GELU, +residual)
 //   -> [post-LN: encoder.layer_norm] -> NL x { q|k|v GEMM, attention, out_proj(+residual), LN, fc1(+GELU),
 //   fc2(+residual), LN }  with every hidden-state tap written straight into the caller's (NL+1, B, T, D) slab.
-#include <hip/hip_runtime.h>
+//   (multires-HuBERT continues in multires.hip after post_extract_proj; the single-kernel entry points are in ops.hip)
+#include "engine_internal.h"
 
-#include <algorithm>
-#include <cmath>
-#include <cstdio>
-#include <cstring>
-#include <map>
-#include <string>
-#include <vector>
-
-#include "../../include/s3enc.h"
-#include "kernels.h"
-
-using namespace s3;
-
-namespace {
+namespace s3e {
 
 thread_local std::string g_err;
 int g_x3_pack_cache = 0;
-
-int fail(const std::string& msg) {
-    g_err = msg;
-    return 1;
-}
-
-#define HIP_TRY(expr)                                                                                  \
-    do {                                                                                               \
-        hipError_t _e = (expr);                                                                        \
-        if (_e != hipSuccess) {                                                                        \
-            char _b[512];                                                                              \
-            snprintf(_b, sizeof(_b), "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
-            return fail(_b);                                                                           \
-        }                                                                                              \
-    } while (0)
-
-// ---- host-side dtype conversion -------------------------------------------------------------------------
-inline uint16_t h_bf16(float f) {
-    uint32_t u;
-    memcpy(&u, &f, 4);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
-}
-inline uint16_t h_f16(float f) {
-    _Float16 h = (_Float16)f;
-    uint16_t r;
-    memcpy(&r, &h, 2);
-    return r;
-}
-inline float h_from16(uint16_t v, int dtype) {
-    if (dtype == BF16) {
-        uint32_t u = ((uint32_t)v) << 16;
-        float f;
-        memcpy(&f, &u, 4);
-        return f;
-    }
-    _Float16 h;
-    memcpy(&h, &v, 2);
-    return (float)h;
-}
-
-// bumped by every (re)allocation of a DevBuf: a captured forward graph bakes workspace addresses in, so a graph made
-// under an older generation is discarded and re-captured (s3enc_set_graph_replay)
 unsigned long g_devbuf_gen = 0;
 
-struct DevBuf {
-    void* p = nullptr;
-    size_t bytes = 0;
-    ~DevBuf() {
-        if (p) (void)hipFree(p);
-    }
-    DevBuf() = default;
-    DevBuf(const DevBuf&) = delete;
-    DevBuf& operator=(const DevBuf&) = delete;
-    DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes) {
-        o.p = nullptr;
-        o.bytes = 0;
-    }
-    hipError_t ensure(size_t n) {
-        if (n <= bytes) return hipSuccess;
-        if (p) {
-            hipError_t e = hipFree(p);  // implicit device sync: nothing in flight still uses it
-            p = nullptr;
-            bytes = 0;
-            if (e != hipSuccess) return e;
-        }
-        hipError_t e = hipMalloc(&p, n);
-        if (e == hipSuccess) bytes = n;
-        ++g_devbuf_gen;
-        return e;
-    }
-    // Growth on the forward path, ordered on `st` instead of synchronising the device: the old block is released with
-    // hipFreeAsync (it may still be read by launches already enqueued on `st`) and the new one comes from the
-    // stream-ordered allocator, 25 % larger than asked so a serving loop with drifting batch shapes settles after a few
-    // growths.  Falls back to the synchronising path if the runtime has no stream-ordered pool.
-    hipError_t ensure_on_stream(size_t n, hipStream_t st) {
-        if (n <= bytes) return hipSuccess;
-        const size_t want = n + n / 4;
-        void* np = nullptr;
-        hipError_t e = hipMallocAsync(&np, want, st);
-        if (e != hipSuccess) {
-            (void)hipGetLastError();
-            return ensure(want);
-        }
-        if (p) {
-            e = hipFreeAsync(p, st);
-            if (e != hipSuccess) {
-                (void)hipGetLastError();
-                (void)hipStreamSynchronize(st);
-                (void)hipFree(p);
-            }
-        }
-        p = np;
-        bytes = want;
-        ++g_devbuf_gen;
-        return hipSuccess;
-    }
-};
-
-// current-device RAII: the entry points never leave the caller's (torch's) current device changed
-struct DeviceGuard {
-    int prev = -1;
-    bool ok = true;
-    explicit DeviceGuard(int dev) {
-        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
-        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
-    }
-    ~DeviceGuard() {
-        int cur = -1;
-        if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
-    }
-};
-
-hipError_t upload_f32(DevBuf& d, const std::vector<float>& v) {
-    hipError_t e = d.ensure(v.size() * 4 + 16);
-    if (e != hipSuccess) return e;
-    return hipMemcpy(d.p, v.data(), v.size() * 4, hipMemcpyHostToDevice);
-}
-hipError_t upload_cvt(DevBuf& d, const std::vector<float>& v, int dtype) {
-    if (dtype == F32) return upload_f32(d, v);
-    std::vector<uint16_t> h(v.size());
-    if (dtype == BF16)
-        for (size_t i = 0; i < v.size(); ++i) h[i] = h_bf16(v[i]);
-    else
-        for (size_t i = 0; i < v.size(); ++i) h[i] = h_f16(v[i]);
-    hipError_t e = d.ensure(h.size() * 2 + 16);
-    if (e != hipSuccess) return e;
-    return hipMemcpy(d.p, h.data(), h.size() * 2, hipMemcpyHostToDevice);
+long conv_len(const s3enc_config& c, long n, int upto /*exclusive*/) {
+    for (int i = 0; i < upto; ++i) n = n >= c.conv_kernel[i] ? (n - c.conv_kernel[i]) / c.conv_stride[i] + 1 : 0;
+    return n;
 }
 
-// Positional-conv weight (folded, [D][Dg][K] like nn.Conv1d.weight) -> the layout of the kernel of `dtype`:
-//   fp32   [G][K][Dg/16][Dg(co)][16]         (posconv_kernel: tap-major 16-deep input-channel chunks)
-//   16-bit [G][Dg(co)][k = tap*Dg + ci]       (posconv16_kernel: the W operand of the implicit GEMM)
-void pack_posconv(const std::vector<float>& w, int D, int G, int K, int dtype, std::vector<float>& out) {
-    const int Dg = D / G;
-    out.assign((size_t)G * K * Dg * Dg, 0.f);
-    for (int gi = 0; gi < G; ++gi)
-        for (int n = 0; n < Dg; ++n)
-            for (int ci = 0; ci < Dg; ++ci)
-                for (int k = 0; k < K; ++k) {
-                    const float x = w[((long)(gi * Dg + n) * Dg + ci) * K + k];
-                    if (dtype == F32)
-                        out[((((long)gi * K + k) * (Dg / 16) + ci / 16) * Dg + n) * 16 + ci % 16] = x;
-                    else
-                        out[(((long)gi * Dg + n) * K + k) * Dg + ci] = x;
-                }
+int valid_frames(const s3enc_config& c, long length, long n_max) {
+    const long T = conv_len(c, n_max, c.n_conv);
+    if (T <= 0) return 0;
+    long v;
+    if (c.family == S3ENC_WAV2VEC2 || c.family == S3ENC_DISTILLER) {
+        v = conv_len(c, length, c.n_conv);  // wav2vec2_model.py:2652-2669; distiller/model.py:271-285
+    } else {
+        const long chunk = n_max / T;  // hubert_model.py:454-464
+        v = (length + chunk - 1) / chunk;
+    }
+    if (v > T) v = T;
+    if (v < 0) v = 0;
+    return (int)v;
 }
-
-// S3ENC_F32X3: upload the pair-packed bf16 hi / lo image of an (N, K) fp32 weight (K % 32 == 0, else left empty: that
-// GEMM then runs on the exact kernel)
-hipError_t upload_x3(DevBuf& d, const std::vector<float>& v, long N, long K) {
-    if (K % 32 || (long)v.size() < N * K) return hipSuccess;
-    std::vector<uint16_t> pk;
-    pack_x3(v.data(), N, K, pk);
-    hipError_t e = d.ensure(pk.size() * 2 + 16);
-    if (e != hipSuccess) return e;
-    return hipMemcpy(d.p, pk.data(), pk.size() * 2, hipMemcpyHostToDevice);
+int num_states(const s3enc_config& c, int selection) {
+    if (c.family == S3ENC_MULTIRES) return c.encoder_layers + 2 * c.mr_pairs + 1;  // per block: layer inputs + its output
+    if (selection == S3ENC_SEL_HIDDEN) return c.encoder_layers + 1 + (c.family == S3ENC_DISTILLER ? c.pred_heads : 0);
+    return c.encoder_layers;
 }
-
-// S3ENC_F32X3 positional conv: the 16-bit layout [G][Dg][K*Dg] as a bf16 hi image followed by the lo image
-hipError_t upload_posconv_x3(DevBuf& d, const std::vector<float>& w, int D, int G, int K) {
-    std::vector<float> lay;
-    pack_posconv(w, D, G, K, BF16, lay);
-    std::vector<uint16_t> img(lay.size() * 2);
-    for (size_t i = 0; i < lay.size(); ++i) {
-        const uint16_t h = h_bf16(lay[i]);
-        img[i] = h;
-        img[lay.size() + i] = h_bf16(lay[i] - h_from16(h, BF16));
-    }
-    hipError_t e = d.ensure(img.size() * 2 + 16);
-    if (e != hipSuccess) return e;
-    return hipMemcpy(d.p, img.data(), img.size() * 2, hipMemcpyHostToDevice);
-}
-
-struct LayerW {
-    DevBuf wqkv, bqkv, wo, bo, ln1g, ln1b, w1, b1, w2, b2, ln2g, ln2b;
-    DevBuf wqkv3, wo3, w13, w23;  // S3ENC_F32X3: pair-packed bf16 hi / lo images of the four weight matrices
-    DevBuf grep_w, grep_b, grep_a;
-};
-struct ConvW {
-    DevBuf w, bias, lng, lnb;  // w: conv0 fp32 [C][k]; conv>=1 compute dtype [C][k*Cin]
-    DevBuf w3;                 // S3ENC_F32X3: pair-packed image of w (conv >= 1)
-    bool has_bias = false;
-};
-
-// multires-HuBERT (multires_hubert/hubert_model.py:337-530): one TransformerEncoder of the U-net, and a conv adapter
-struct BlockW {
-    std::vector<LayerW> layers;
-    DevBuf eln_g, eln_b;  // the block's own encoder.layer_norm
-};
-struct AdapterConvW {
-    DevBuf w, w3;  // the convolution as a GEMM operand (N, K) in the compute dtype (+ the S3ENC_F32X3 image)
-    DevBuf g, b;   // Fp32GroupNorm(1, D) affine
-};
-struct AdapterW {
-    AdapterConvW up, down;  // ConvTranspose1d(stride = up_rate) / Conv1d(stride = down_rate); plain variants hold one
-    int kind = 0;           // 0 ConvAdapter (both), 1 ConvDownsampler, 2 ConvUpsampler
-    int up_rate = 1, down_rate = 1;
-};
-
-struct ProfRec {
-    int kind;
-    hipEvent_t a, b;
-};
-
-}  // namespace
-
-struct s3enc_encoder {
-    s3enc_config cfg;
-    int device = 0;
-    int dtype = F32;
-    bool x3 = false;  // S3ENC_F32X3
-    int es = 4;  // element size of the compute dtype
-    std::vector<ConvW> conv;
-    DevBuf gn_g, gn_b;
-    DevBuf fln_g, fln_b, proj_w, proj_b, pos_w, pos_b, eln_g, eln_b;
-    DevBuf proj_w3, pos_w3;  // S3ENC_F32X3
-    std::vector<LayerW> layers;
-    DevBuf rel_table;  // WavLM: [H][2R+1], entry (h, rel + R), R = max_distance (the bucket saturates there)
-    int rel_R = 0;
-    // data2vec positional-conv stack (cfg.pos_conv_depth > 1): per block the packed conv weight + bias; pos_k = the kernel
-    // width as packed (zero taps appended so that the 16-bit implicit GEMM's k axis is a multiple of 128), pos_pad = the
-    // real kernel's K / 2; ones / zeros = the affine of LayerNorm(elementwise_affine=False)
-    std::vector<DevBuf> pos_ws, pos_bs;
-    int pos_k = 0, pos_pad = 0;
-    DevBuf ones, zeros;
-    DevBuf head_w1, head_b1, head_w2, head_b2, head_w13, head_w23;  // DistilHuBERT prediction heads (+ S3ENC_F32X3 images)
-    DevBuf wsum_part;  // persistent partials of s3enc_weighted_sum_backward
-    std::vector<BlockW> mr_blocks;      // S3ENC_MULTIRES: encoders..., middle_encoder, decoders... (execution order)
-    std::vector<AdapterW> mr_adapters;  // downsample_modules[0..R-2], then upsample_modules[0..R-2]
-    DevBuf ws_mr;                       // activation workspace of the U-net behind post_extract_proj
-
-    // hipGraph replay of repeated forwards (s3enc_set_graph_replay): one executable graph per (batch shape, state
-    // selection, output block).  The per-call data — waveform pointers, lengths, valid frames — reach the kernels through
-    // the device table that is uploaded BEFORE the graph is launched, so a replay is: table upload + one hipGraphLaunch.
-    struct GraphSlot {
-        int B = 0;
-        long n_max = 0;
-        int selection = 0, out_dtype = 0;
-        const void* out = nullptr;
-        long stride = 0;
-        hipGraphExec_t exec = nullptr;
-        unsigned long gen = 0;  // g_devbuf_gen the graph was captured under
-        int seen = 0;           // successful eager forwards with this key (the first one sizes workspaces and LDS attributes)
-        unsigned long used = 0;
-    };
-    int graphs_on = 0;
-    std::vector<GraphSlot> graphs;
-    unsigned long graph_clock = 0;
-    long graph_replays = 0, graph_captures = 0;
-    bool capture_aborted = false;
-    // the NULL (legacy default) stream cannot be captured: with graph replay on, a forward submitted to it runs on this
-    // private stream instead, fenced by events on both sides (ordered after the caller's earlier work, before its later work)
-    hipStream_t graph_stream = nullptr;
-    hipEvent_t graph_ev_in = nullptr, graph_ev_out = nullptr;
-
-    DevBuf ws;      // activation workspace
-    DevBuf small;   // tables, stats
-    void* pinned = nullptr;  // host staging ring
-    static constexpr int RING = 4;
-    size_t slot_bytes = 0;
-    hipEvent_t slot_ev[RING] = {};
-    int slot_next = 0;
-
-    std::vector<hipEvent_t> layer_events;  // caller-owned, recorded when hidden_states[l] is final
-
-    // profiling
-    int prof = 0;  // 0 off, 1 every kernel, 2 only the GEMM launches (the dominant kernel: cheap enough for a timed region)
-    std::vector<std::string> kinds;
-    std::vector<double> kflops, kbytes;
-    std::vector<long> klaunches;
-    std::vector<ProfRec> recs;
-    std::vector<hipEvent_t> ev_pool;  // timing events are recycled across profile_reset, never created per forward twice
-
-    // debug taps of the last forward
-    struct Tap {
-        const void* p;
-        long elems;
-        int dtype;
-    };
-    std::map<std::string, Tap> taps;
-
-    ~s3enc_encoder() {
-        for (auto& r : recs) {
-            (void)hipEventDestroy(r.a);
-            (void)hipEventDestroy(r.b);
-        }
-        for (auto ev : ev_pool) (void)hipEventDestroy(ev);
-        for (auto& g : graphs)
-            if (g.exec) (void)hipGraphExecDestroy(g.exec);
-        if (graph_ev_in) (void)hipEventDestroy(graph_ev_in);
-        if (graph_ev_out) (void)hipEventDestroy(graph_ev_out);
-        if (graph_stream) (void)hipStreamDestroy(graph_stream);
-        for (int i = 0; i < RING; ++i)
-            if (slot_ev[i]) (void)hipEventDestroy(slot_ev[i]);
-        if (pinned) (void)hipHostFree(pinned);
-    }
-
-    int kind_id(const char* name) {
-        for (size_t i = 0; i < kinds.size(); ++i)
-            if (kinds[i] == name) return (int)i;
-        kinds.push_back(name);
-        kflops.push_back(0);
-        kbytes.push_back(0);
-        klaunches.push_back(0);
-        return (int)kinds.size() - 1;
-    }
-    bool take_event(hipEvent_t* ev) {
-        if (!ev_pool.empty()) {
-            *ev = ev_pool.back();
-            ev_pool.pop_back();
-            return true;
-        }
-        return hipEventCreate(ev) == hipSuccess;
-    }
-};
+}  // namespace s3e
 
 namespace {
-
-struct Prof {
-    s3enc_encoder* e;
-    hipStream_t st;
-    int idx = -1;
-    Prof(s3enc_encoder* enc, hipStream_t s, const char* kind, double flops, double bytes) : e(enc), st(s) {
-        if (!e || !e->prof) return;
-        if (e->prof == 2 && strncmp(kind, "gemm", 4) != 0) return;
-        const int k = e->kind_id(kind);
-        e->kflops[k] += flops;
-        e->kbytes[k] += bytes;
-        e->klaunches[k] += 1;
-        ProfRec r;
-        r.kind = k;
-        if (!e->take_event(&r.a)) return;
-        if (!e->take_event(&r.b)) {
-            e->ev_pool.push_back(r.a);
-            return;
-        }
-        (void)hipEventRecord(r.a, st);
-        e->recs.push_back(r);
-        idx = (int)e->recs.size() - 1;
-    }
-    ~Prof() {
-        if (idx >= 0) (void)hipEventRecord(e->recs[idx].b, st);
-    }
-};
 
 // ---- checkpoint lookup ---------------------------------------------------------------------------------------
 struct Ckpt {
@@ -397,107 +68,6 @@ bool fetch(const Ckpt& c, const std::string& name, long expect, std::vector<floa
     out.assign(t->data, t->data + expect);
     return true;
 }
-
-long conv_len(const s3enc_config& c, long n, int upto /*exclusive*/) {
-    for (int i = 0; i < upto; ++i) n = n >= c.conv_kernel[i] ? (n - c.conv_kernel[i]) / c.conv_stride[i] + 1 : 0;
-    return n;
-}
-
-int valid_frames(const s3enc_config& c, long length, long n_max) {
-    const long T = conv_len(c, n_max, c.n_conv);
-    if (T <= 0) return 0;
-    long v;
-    if (c.family == S3ENC_WAV2VEC2 || c.family == S3ENC_DISTILLER) {
-        v = conv_len(c, length, c.n_conv);  // wav2vec2_model.py:2652-2669; distiller/model.py:271-285
-    } else {
-        const long chunk = n_max / T;  // hubert_model.py:454-464
-        v = (length + chunk - 1) / chunk;
-    }
-    if (v > T) v = T;
-    if (v < 0) v = 0;
-    return (int)v;
-}
-
-// ---- multires-HuBERT frame geometry (mirrors EncoderConfig.multires_plan in s3prl_amd/config.py) ----------------
-struct MrBlockPlan {
-    int layers;
-    long T;       // frames the block runs on
-    int factor;   // repeat_interleave factor of its states (multires_hubert/expert.py:41-47)
-    int adapter;  // index into mr_adapters of the conv adapter applied before the block, -1 for the first
-    long T_in;    // frames entering that adapter
-    long T_sum;   // decoders: min(T, residual frames) of align_size_sum (hubert_model.py:777-783)
-};
-struct MrPlan {
-    std::vector<MrBlockPlan> blocks;
-    long T_out = 0;  // common length every (repeated) state is cut to (expert.py:93-101)
-};
-
-// output frames of a conv adapter on T frames (hubert_model.py:1038-1095,1146-1180,1232-1266): each stage is cut to
-// min(conv length, skip-connection length); kind 0 ConvAdapter, 1 ConvDownsampler, 2 ConvUpsampler
-long mr_adapter_frames(int k, long T, int up, int down, int kind) {
-    long n = T;
-    if (kind != 1) n = std::min<long>((long)up * T + k - 1, (long)up * T);
-    if (kind != 2) {
-        const long ld = (n + 2 * ((k - 1) / 2) - k) / down + 1;
-        const long n2 = std::min(ld, (n + down - 1) / down);
-        n = kind == 0 ? std::min(n2, ((long)up * T + down - 1) / down) : n2;
-    }
-    return n;
-}
-
-void mr_plan(const s3enc_config& c, long T0, MrPlan& plan) {
-    const int R = c.mr_pairs + 1, k = c.mr_kernel;
-    long ds[S3ENC_MAX_RES], lcm = 1;
-    ds[0] = 1;
-    for (int i = 0; i < c.n_conv; ++i) ds[0] *= c.conv_stride[i];
-    for (int i = 0; i < R - 1; ++i) ds[i + 1] = ds[i] * c.mr_ratios[2 * i + 1] / c.mr_ratios[2 * i];  // hubert_model.py:512-533
-    for (int i = 0; i < R; ++i) {
-        long a = lcm, b = ds[i];
-        while (b) {
-            const long r = a % b;
-            a = b;
-            b = r;
-        }
-        lcm = lcm / a * ds[i];
-    }
-    int upf[S3ENC_MAX_RES], rev[S3ENC_MAX_RES];
-    for (int i = 0; i < R; ++i) upf[i] = (int)(lcm / ds[R - 1 - i]);  // (sic) the expert reverses the list, expert.py:44-45
-    for (int i = 0; i + 1 < R; ++i) rev[i] = upf[R - 2 - i];           // upsample_factor[::-1][1:]
-    plan.blocks.clear();
-    long T = T0, encT[S3ENC_MAX_RES];
-    int ad = -1;
-    long t_in = 0;
-    for (int i = 0; i < R - 1; ++i) {
-        plan.blocks.push_back({c.mr_layers[i], T, upf[i], ad, t_in, T});
-        encT[i] = T;
-        ad = i;
-        t_in = T;
-        T = mr_adapter_frames(k, T, c.mr_ratios[2 * i], c.mr_ratios[2 * i + 1], c.mr_plain ? 1 : 0);
-    }
-    plan.blocks.push_back({c.mr_layers[R - 1], T, upf[R - 1], ad, t_in, T});
-    for (int i = 0; i < R - 1; ++i) {
-        t_in = T;
-        T = mr_adapter_frames(k, T, c.mr_ratios[2 * i + 1], c.mr_ratios[2 * i], c.mr_plain ? 2 : 0);
-        const long res = encT[R - 2 - i];
-        plan.blocks.push_back({c.mr_layers[R + i], T, rev[i], R - 1 + i, t_in, std::min(T, res)});
-        T = std::min(T, res);
-    }
-    plan.T_out = -1;
-    for (const auto& b : plan.blocks) {
-        const long a = b.T * b.factor, p2 = (b.T + (b.T & 1)) * b.factor;  // outputs; layer inputs are padded to even T
-        const long m = std::min(a, p2);
-        if (plan.T_out < 0 || m < plan.T_out) plan.T_out = m;
-    }
-}
-
-long output_frames(const s3enc_config& c, long n_samples) {
-    const long T = conv_len(c, n_samples, c.n_conv);
-    if (c.family != S3ENC_MULTIRES || T < 1) return T;
-    MrPlan plan;
-    mr_plan(c, T, plan);
-    return plan.T_out;
-}
-
 // WavLM bucket table (wavlm/modules.py:418-462): table[h][rel + R] = E[bucket(rel)][h] for rel = key - query in [-R, R]
 void build_rel_table(const s3enc_config& c, const std::vector<float>& emb, int R, std::vector<float>& table) {
     const int H = c.heads, nb = c.num_buckets / 2, max_exact = nb / 2;
@@ -564,7 +134,6 @@ int check_config(const s3enc_config& c) {
     if (c.pos_conv_depth > 1 && c.family != S3ENC_WAV2VEC2) return fail("config: pos_conv_depth > 1 is the data2vec-audio encoder (wav2vec2 family)");
     return 0;
 }
-
 }  // namespace
 
 extern "C" {
@@ -919,32 +488,6 @@ int s3enc_valid_frames(s3enc_handle h, int64_t length, int64_t n_max, int32_t* v
 
 namespace {
 
-// bump allocator over the workspace
-struct Bump {
-    char* base;
-    size_t off = 0;
-    explicit Bump(void* b) : base((char*)b) {}
-    void* take(size_t bytes) {
-        void* p = base ? base + off : nullptr;
-        off += (bytes + 255) & ~(size_t)255;
-        return p;
-    }
-};
-
-struct FwdOpts {
-    int selection = S3ENC_SEL_HIDDEN;
-    int out_dtype = F32;
-    bool featurize = false;
-    int feat_norm = 0;
-    const float* w = nullptr;  // host, one per state
-};
-
-int num_states(const s3enc_config& c, int selection) {
-    if (c.family == S3ENC_MULTIRES) return c.encoder_layers + 2 * c.mr_pairs + 1;  // per block: layer inputs + its output
-    if (selection == S3ENC_SEL_HIDDEN) return c.encoder_layers + 1 + (c.family == S3ENC_DISTILLER ? c.pred_heads : 0);
-    return c.encoder_layers;
-}
-
 // Where the selected states go: straight into the caller's fp32 slab (the producing kernel writes the slot, nothing is
 // copied), as 16-bit copies next to an internal fp32 residual stream, or only as their term of the Featurizer sum.
 struct Sink {
@@ -1032,415 +575,6 @@ struct CaptureGuard {
         return 0;
     }
 };
-
-// ---- multires-HuBERT behind post_extract_proj (multires_hubert/hubert_model.py:786-822) -------------------------------
-// x (B, T0, D) fp32 with the padded frames zeroed -> encoders[i] -> conv adapter (down) ... middle_encoder (+ its input) ...
-// conv adapter (up) -> decoders[i] (+ the matching encoder's output).  Every block's layer inputs and its output are
-// states; each is written to its (B, T_out, D) slot with its frames repeated `factor` times (expert.py:26-27,93-101).
-// The blocks run the same GEMM / attention / LayerNorm kernels as the single-resolution encoders; the adapter
-// convolutions are GEMMs over zero-bordered frame buffers, their GroupNorm / GELU / skip passes are adapter.hip.
-int multires_tail(s3enc_handle e, hipStream_t st, int B, const MrPlan& plan, const std::vector<const int*>& d_valid, float* xproj,
-                  void* out, long layer_stride, const FwdOpts& fo) {
-    const s3enc_config& c = e->cfg;
-    const int D = c.embed_dim, F = c.ffn_dim, H = c.heads;
-    const int dt = e->dtype, es = e->es;
-    const bool prel = c.layer_norm_first != 0;
-    const int R = c.mr_pairs + 1, NB = 2 * R - 1, k = c.mr_kernel, PADR = k - 1;
-    const bool out16 = !fo.featurize && fo.out_dtype != F32;
-    const float scale = std::sqrt(0.4f);  // sqrt(residual_scale), hubert_model.py:429,1036
-
-    // capacities: frames of the widest block, rows of the widest zero-bordered operand, frames of the longest conv output
-    long Tc = 0, Pc = 0, Lc = 0;
-    for (const auto& bp : plan.blocks) {
-        Tc = std::max(Tc, bp.T);
-        if (bp.adapter < 0) continue;
-        const AdapterW& aw = e->mr_adapters[bp.adapter];
-        long rows = bp.T_in;
-        Pc = std::max(Pc, rows + 2 * PADR);
-        if (aw.kind != 1) {
-            Lc = std::max(Lc, (rows + (k - 1) / aw.up_rate) * aw.up_rate);
-            rows *= aw.up_rate;
-            Pc = std::max(Pc, rows + 2 * PADR);
-        }
-        if (aw.kind != 2) Lc = std::max(Lc, (rows - 1) / aw.down_rate + 1);
-    }
-    const long Mc = (long)B * Tc;
-    float *hA, *hB, *yM, *bufX, *tmp1, *tmp2, *pad32[2], *convout, *res[S3ENC_MAX_RES] = {};
-    void *xT, *qkv, *attn, *hbuf, *pad16[2] = {};
-    double* gpart;
-    for (int pass = 0; pass < 2; ++pass) {
-        Bump wb(pass ? e->ws_mr.p : nullptr);
-        hA = (float*)wb.take((size_t)Mc * D * 4);
-        hB = (float*)wb.take((size_t)Mc * D * 4);
-        yM = (float*)wb.take((size_t)Mc * D * 4);
-        bufX = (float*)wb.take((size_t)Mc * D * 4);
-        tmp1 = (float*)wb.take((size_t)Mc * D * 4);
-        tmp2 = (float*)wb.take((size_t)Mc * D * 4);
-        xT = wb.take((size_t)Mc * D * 4);
-        qkv = wb.take((size_t)Mc * 3 * D * es);
-        attn = wb.take((size_t)Mc * D * es);
-        hbuf = wb.take((size_t)Mc * F * es);
-        for (int i = 0; i < R - 1; ++i) res[i] = (float*)wb.take((size_t)B * plan.blocks[i].T * D * 4);
-        for (int i = 0; i < 2; ++i) {
-            pad32[i] = (float*)wb.take((size_t)B * Pc * D * 4);
-            if (dt != F32) pad16[i] = wb.take((size_t)B * Pc * D * 2);
-        }
-        convout = (float*)wb.take((size_t)B * Lc * D * 4);
-        gpart = (double*)wb.take((size_t)B * GS_BLOCKS * 2 * 8);
-        if (!pass) HIP_TRY(e->ws_mr.ensure_on_stream(wb.off + 4096, st));
-    }
-
-    int si = 0;
-    bool first_term = true;
-    // a state (B, T, D) -> slot si of the caller's slab at the finest frame rate; featurize: only its term of the sum
-    auto emit = [&](const float* x, long T, int factor) -> int {
-        if (fo.featurize) {
-            if (fo.w[si] != 0.f) {
-                LnAcc fa;
-                fa.acc = (float*)out;
-                fa.w = fo.w[si];
-                fa.mode = 1;
-                fa.norm = fo.feat_norm;
-                fa.init = first_term;
-                first_term = false;
-                Prof pr(e, st, "emit_state", 0, (double)B * plan.T_out * D * (4.0 / factor + 8));
-                HIP_TRY(launch_emit_upsampled_acc(x, T * D, factor, B, (int)plan.T_out, D, fa, st));
-            }
-            ++si;
-            return 0;
-        }
-        float* o32 = out16 ? nullptr : (float*)out + (long)si * layer_stride;
-        void* o16 = out16 ? (void*)((u16*)out + (long)si * layer_stride) : nullptr;
-        {
-            Prof pr(e, st, "emit_state", 0, (double)B * plan.T_out * D * (4.0 / factor + (out16 ? 2 : 4)));
-            HIP_TRY(launch_emit_upsampled(out16 ? dt : (int)F32, x, T * D, factor, B, (int)plan.T_out, D, o32, o16, st));
-        }
-        if (si < (int)e->layer_events.size()) HIP_TRY(hipEventRecord(e->layer_events[si], st));
-        ++si;
-        return 0;
-    };
-
-    // one TransformerEncoder of the U-net (wav2vec2_model.py:3046-3121 with skip_pos_conv / override_encoder_layer):
-    // x (B, T, D) fp32, padded frames zero (the producer wrote them so); the block's output lands in y_out
-    auto run_block = [&](int bi, float* x, float* y_out) -> int {
-        BlockW& bw = e->mr_blocks[bi];
-        const MrBlockPlan& bp = plan.blocks[bi];
-        const long T = bp.T, M = (long)B * T;
-        const double gM = (double)M;
-        const int NLb = (int)bw.layers.size();
-        float* cur = x;
-        auto pick = [&](const float* busy) { return busy == hA ? hB : hA; };
-        if (bi == 0) {  // only encoders[0] keeps the positional conv (hubert_model.py:434-449)
-            PosConvParams p{};
-            p.x = x;
-            p.w = e->x3 ? e->pos_w3.p : e->pos_w.p;
-            p.bias = (const float*)e->pos_b.p;
-            p.out = hA;
-            p.B = B;
-            p.T = (int)T;
-            p.D = D;
-            p.G = c.conv_pos_groups;
-            p.K = c.conv_pos;
-            Prof pr(e, st, "posconv", 2.0 * gM * D * (D / p.G) * p.K, gM * D * 8 + (double)D * (D / p.G) * p.K * 4);
-            HIP_TRY(e->x3 ? launch_posconv16(3, p, st) : (dt == F32 ? launch_posconv(p, st) : launch_posconv16(dt, p, st)));
-            cur = hA;
-        }
-        if (!prel) {
-            float* h0 = pick(cur);
-            Prof pr(e, st, "layernorm:enc", 0, gM * D * (8 + (dt == F32 ? 0 : es)));
-            HIP_TRY(launch_layernorm(dt, cur, (const float*)bw.eln_g.p, (const float*)bw.eln_b.p, M, D, 0, h0,
-                                     dt == F32 ? nullptr : xT, st));
-            cur = h0;
-        }
-        if (emit(cur, T, bp.factor)) return 1;  // the input of the block's first layer
-        for (int l = 0; l < NLb; ++l) {
-            LayerW& Lw = bw.layers[l];
-            const bool lastl = l == NLb - 1;
-            const void* a_in;
-            if (prel) {
-                Prof pr(e, st, "layernorm:ln1", 0, gM * D * (4 + es));
-                HIP_TRY(launch_layernorm(dt, cur, (const float*)Lw.ln1g.p, (const float*)Lw.ln1b.p, M, D, 0,
-                                         dt == F32 ? (float*)xT : nullptr, dt == F32 ? nullptr : xT, st));
-                a_in = xT;
-            } else {
-                a_in = dt == F32 ? (const void*)cur : (const void*)xT;
-            }
-            {
-                GemmParams g{};
-                g.A = a_in;
-                g.lda = D;
-                g.W = Lw.wqkv.p;
-                g.W_x3 = Lw.wqkv3.p;
-                g.bias = (const float*)Lw.bqkv.p;
-                g.M = (int)M;
-                g.N = 3 * D;
-                g.K = D;
-                g.batches = 1;
-                g.ldo = 3 * D;
-                if (dt == F32) g.out32 = (float*)qkv; else g.out16 = qkv;
-                Prof pr(e, st, "gemm:qkv", 2.0 * gM * 3 * D * D, (gM * D + 3.0 * D * D + gM * 3 * D) * es);
-                HIP_TRY(launch_gemm(dt, g, st));
-            }
-            {
-                AttnParams a{};
-                a.qkv = qkv;
-                a.out = attn;
-                a.valid = d_valid[bi];
-                a.B = B;
-                a.T = (int)T;
-                a.H = H;
-                Prof pr(e, st, "attention", 4.0 * B * H * (double)T * T * 64, gM * 4 * D * es);
-                HIP_TRY(launch_attention(e->x3 ? 3 : dt, a, st));
-            }
-            {
-                GemmParams g{};
-                g.A = attn;
-                g.lda = D;
-                g.W = Lw.wo.p;
-                g.W_x3 = Lw.wo3.p;
-                g.bias = (const float*)Lw.bo.p;
-                g.M = (int)M;
-                g.N = D;
-                g.K = D;
-                g.batches = 1;
-                g.ldo = D;
-                g.residual = cur;
-                g.out32 = tmp1;
-                Prof pr(e, st, "gemm:out_proj", 2.0 * gM * D * D, (gM * D + (double)D * D) * es + gM * D * 8);
-                HIP_TRY(launch_gemm(dt, g, st));
-            }
-            const float* ffn_res;
-            const void* ffn_in;
-            if (prel) {
-                Prof pr(e, st, "layernorm:ln2", 0, gM * D * (4 + es));
-                HIP_TRY(launch_layernorm(dt, tmp1, (const float*)Lw.ln2g.p, (const float*)Lw.ln2b.p, M, D, 0,
-                                         dt == F32 ? (float*)xT : nullptr, dt == F32 ? nullptr : xT, st));
-                ffn_res = tmp1;
-                ffn_in = xT;
-            } else {
-                Prof pr(e, st, "layernorm:ln1", 0, gM * D * (8 + (dt == F32 ? 0 : es)));
-                HIP_TRY(launch_layernorm(dt, tmp1, (const float*)Lw.ln1g.p, (const float*)Lw.ln1b.p, M, D, 0, tmp2,
-                                         dt == F32 ? nullptr : xT, st));
-                ffn_res = tmp2;
-                ffn_in = dt == F32 ? (const void*)tmp2 : (const void*)xT;
-            }
-            {
-                GemmParams g{};
-                g.A = ffn_in;
-                g.lda = D;
-                g.W = Lw.w1.p;
-                g.W_x3 = Lw.w13.p;
-                g.bias = (const float*)Lw.b1.p;
-                g.M = (int)M;
-                g.N = F;
-                g.K = D;
-                g.batches = 1;
-                g.act = 1;
-                g.ldo = F;
-                if (dt == F32) g.out32 = (float*)hbuf; else g.out16 = hbuf;
-                Prof pr(e, st, "gemm:fc1", 2.0 * gM * F * D, (gM * D + (double)F * D + gM * F) * es);
-                HIP_TRY(launch_gemm(dt, g, st));
-            }
-            float* nxt = (!prel && lastl) ? y_out : pick(cur);
-            {
-                GemmParams g{};
-                g.A = hbuf;
-                g.lda = F;
-                g.W = Lw.w2.p;
-                g.W_x3 = Lw.w23.p;
-                g.bias = (const float*)Lw.b2.p;
-                g.M = (int)M;
-                g.N = D;
-                g.K = F;
-                g.batches = 1;
-                g.ldo = D;
-                g.residual = ffn_res;
-                g.out32 = prel ? nxt : tmp1;
-                Prof pr(e, st, "gemm:fc2", 2.0 * gM * D * F, (gM * F + (double)D * F) * es + gM * D * 8);
-                HIP_TRY(launch_gemm(dt, g, st));
-            }
-            if (!prel) {
-                Prof pr(e, st, "layernorm:ln2", 0, gM * D * (8 + (dt == F32 ? 0 : es)));
-                HIP_TRY(launch_layernorm(dt, tmp1, (const float*)Lw.ln2g.p, (const float*)Lw.ln2b.p, M, D, 0, nxt,
-                                         dt == F32 ? nullptr : xT, st));
-            }
-            cur = nxt;
-            // post-LN: the layer output is the next layer's input / the block output; pre-LN: the last stream is not a state
-            if (!prel || !lastl)
-                if (emit(cur, T, bp.factor)) return 1;
-        }
-        if (prel) {  // encoder.layer_norm on the last residual stream (wav2vec2_model.py:3049-3050): the block output
-            {
-                Prof pr(e, st, "layernorm:enc", 0, gM * D * 8);
-                HIP_TRY(launch_layernorm(F32, cur, (const float*)bw.eln_g.p, (const float*)bw.eln_b.p, M, D, 0, y_out, nullptr, st));
-            }
-            if (emit(y_out, T, bp.factor)) return 1;
-        }
-        return 0;
-    };
-
-    // One convolution + GroupNorm(1, D) statistics of a conv adapter stage: A rows are k_eff * D contiguous elements of the
-    // zero-bordered buffer (lead = PADR rows), output (B, L, D) fp32 in convout; returns L through `frames`
-    auto run_conv = [&](const AdapterConvW& cw, bool transposed, int stride, int which, long rows, long* frames) -> int {
-        const long total = rows + 2 * PADR;
-        GemmParams g{};
-        const char* base = dt == F32 ? (const char*)pad32[which] : (const char*)pad16[which];
-        long Mrows;
-        if (transposed) {
-            const int KT = (k + stride - 1) / stride;
-            Mrows = rows + (k - 1) / stride;  // Q; the (Q, stride * D) output is the (stride * Q, D) sequence
-            g.A = base + (size_t)(PADR - (KT - 1)) * D * es;
-            g.lda = D;
-            g.N = stride * D;
-            g.K = KT * D;
-            *frames = Mrows * stride;
-        } else {
-            const int pd = (k - 1) / 2;
-            Mrows = (rows + 2 * pd - k) / stride + 1;
-            g.A = base + (size_t)(PADR - pd) * D * es;
-            g.lda = (long)stride * D;
-            g.N = D;
-            g.K = k * D;
-            *frames = Mrows;
-        }
-        g.a_bs = total * D;
-        g.W = cw.w.p;
-        g.W_x3 = cw.w3.p;
-        g.M = (int)Mrows;
-        g.batches = B;
-        g.out32 = convout;
-        g.ldo = g.N;
-        g.o_bs = *frames * D;
-        {
-            // algorithmic flops: the k real taps (the zero taps that square up the transposed conv's phases are not counted)
-            Prof pr(e, st, "gemm:adapter", 2.0 * B * (transposed ? (double)rows : (double)Mrows) * D * D * k,
-                    ((double)B * total * D + (double)g.N * g.K) * es + (double)B * *frames * D * 4);
-            HIP_TRY(launch_gemm(dt, g, st));
-        }
-        Prof pr(e, st, "adapter_stats", 0, (double)B * *frames * D * 4);
-        HIP_TRY(launch_group1_stats(convout, *frames * D, *frames * D, B, gpart, st));
-        return 0;
-    };
-
-    // a conv adapter (hubert_model.py:1038-1078 ConvAdapter, :1146-1167 ConvDownsampler, :1232-1250 ConvUpsampler):
-    // input rows a[t] (+ b2[t]) of T_in frames -> bufX (B, n_out, D) fp32 with the frames >= zero_next[b] zeroed
-    auto run_adapter = [&](const AdapterW& aw, const float* a, long a_bs, const float* b2, long b_bs, long T_in, const int* zero_next,
-                           long n_expect) -> int {
-        {
-            PadCopyParams pc{};
-            pc.a = a;
-            pc.a_bs = a_bs;
-            pc.b = b2;
-            pc.b_bs = b_bs;
-            pc.B = B;
-            pc.rows = (int)T_in;
-            pc.D = D;
-            pc.lead = PADR;
-            pc.total = (int)(T_in + 2 * PADR);
-            pc.out32 = pad32[0];
-            pc.out16 = pad16[0];
-            Prof pr(e, st, "adapter_pad", 0, (double)B * T_in * D * (b2 ? 8 : 4) + (double)B * pc.total * D * (4 + (dt == F32 ? 0 : 2)));
-            HIP_TRY(launch_pad_copy(dt, pc, st));
-        }
-        const long total0 = T_in + 2 * PADR;
-        long rows = T_in, frames = 0;
-        int cur = 0;  // operand buffer holding the current stage's input
-        AdapterApplyParams ap{};
-        ap.conv = convout;
-        ap.partial = gpart;
-        ap.scale = scale;
-        ap.B = B;
-        ap.D = D;
-        ap.fast_gelu = e->x3;
-        if (aw.kind != 1) {  // upsample_conv + skip from repeat_interleave(x, up)
-            if (run_conv(aw.up, true, aw.up_rate, cur, rows, &frames)) return 1;
-            const long n1 = std::min(frames, rows * aw.up_rate);
-            ap.conv_bs = frames * D;
-            ap.count = (double)frames * D;
-            ap.gamma = (const float*)aw.up.g.p;
-            ap.beta = (const float*)aw.up.b.p;
-            ap.r1 = pad32[0] + (long)PADR * D;
-            ap.r1_bs = total0 * D;
-            ap.r1_mul = 1;
-            ap.r1_div = aw.up_rate;
-            ap.r2 = nullptr;
-            ap.rows = (int)n1;
-            const bool fin = aw.kind == 2;
-            ap.lead = fin ? 0 : PADR;
-            ap.total = (int)(fin ? n1 : n1 + 2 * PADR);
-            ap.zero_from = fin ? zero_next : nullptr;
-            ap.out32 = fin ? bufX : pad32[1];
-            ap.out16 = fin ? nullptr : pad16[1];
-            Prof pr(e, st, "adapter_apply", 0, (double)B * n1 * D * 12);
-            HIP_TRY(launch_adapter_apply(dt, ap, st));
-            rows = n1;
-            cur = 1;
-        }
-        if (aw.kind != 2) {  // downsample_conv + skip x[::down] (+ highway repeat_interleave(x0, up)[::down])
-            if (run_conv(aw.down, false, aw.down_rate, cur, rows, &frames)) return 1;
-            const long n2 = std::min(frames, (rows + aw.down_rate - 1) / aw.down_rate);
-            const long n3 = aw.kind == 0 ? std::min(n2, (T_in * aw.up_rate + aw.down_rate - 1) / aw.down_rate) : n2;
-            ap.conv_bs = frames * D;
-            ap.count = (double)frames * D;
-            ap.gamma = (const float*)aw.down.g.p;
-            ap.beta = (const float*)aw.down.b.p;
-            ap.r1 = pad32[cur] + (long)PADR * D;
-            ap.r1_bs = (rows + 2 * PADR) * D;
-            ap.r1_mul = aw.down_rate;
-            ap.r1_div = 1;
-            if (aw.kind == 0) {
-                ap.r2 = pad32[0] + (long)PADR * D;
-                ap.r2_bs = total0 * D;
-                ap.r2_mul = aw.down_rate;
-                ap.r2_div = aw.up_rate;
-            } else {
-                ap.r2 = nullptr;
-            }
-            ap.rows = (int)n3;
-            ap.lead = 0;
-            ap.total = (int)n3;
-            ap.zero_from = zero_next;
-            ap.out32 = bufX;
-            ap.out16 = nullptr;
-            Prof pr(e, st, "adapter_apply", 0, (double)B * n3 * D * (aw.kind == 0 ? 16 : 12));
-            HIP_TRY(launch_adapter_apply(dt, ap, st));
-            rows = n3;
-        }
-        if (rows != n_expect) return fail("multires: adapter length does not match the plan (internal error)");
-        return 0;
-    };
-
-    float* x = xproj;
-    for (int bi = 0; bi < NB; ++bi) {
-        const MrBlockPlan& bp = plan.blocks[bi];
-        if (bp.adapter >= 0) {
-            const AdapterW& aw = e->mr_adapters[bp.adapter];
-            const float *a, *b2 = nullptr;
-            long a_bs, b_bs = 0;
-            if (bi <= R - 1) {  // an encoder's output -> downsample_modules[bi - 1]
-                a = res[bi - 1];
-                a_bs = plan.blocks[bi - 1].T * D;
-            } else if (bi == R) {  // x = x + middle_encoder(x) (hubert_model.py:801-802): x is the middle block's zeroed input
-                a = bufX;
-                a_bs = plan.blocks[bi - 1].T * D;
-                b2 = yM;
-                b_bs = a_bs;
-            } else {  // align_size_sum(decoder output, the matching encoder output) (:816)
-                const int ri = R - 2 - (bi - 1 - R);
-                a = yM;
-                a_bs = plan.blocks[bi - 1].T * D;
-                b2 = res[ri];
-                b_bs = plan.blocks[ri].T * D;
-            }
-            if (run_adapter(aw, a, a_bs, b2, b_bs, bp.T_in, d_valid[bi], bp.T)) return 1;
-            x = bufX;
-        }
-        if (run_block(bi, x, bi < R - 1 ? res[bi] : yM)) return 1;
-    }
-    if (si != num_states(c, S3ENC_SEL_HIDDEN)) return fail("multires: state count mismatch (internal error)");
-    return 0;
-}
-
 int forward_once(s3enc_handle e, const float* const* wav_ptrs_host, const int64_t* lengths, int32_t B, int64_t n_max_in,
                  const FwdOpts& fo, void* out, int64_t layer_stride, hipStream_t st);
 
@@ -2094,7 +1228,6 @@ int forward_once(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
     }
     return cap.finish();
 }
-
 }  // namespace
 
 extern "C" {
@@ -2237,272 +1370,4 @@ int s3enc_debug_tap(s3enc_handle h, const char* name, float* host_out, int64_t m
     }
     return 0;
 }
-
-int s3enc_set_tuning(const char* key, int32_t value) {
-    if (!key) return fail("s3enc_set_tuning: null key");
-    if (!strcmp(key, "gemm_variant")) {
-        if (value < 0 || value > 63) return fail("gemm_variant must be 0..63");
-        g_gemm_variant = value;
-        return 0;
-    }
-    if (!strcmp(key, "gemm16_big")) {
-        if (value < 0 || value > 9) return fail("gemm16_big must be 0..9");
-        g_gemm16_big = value;
-        return 0;
-    }
-    if (!strcmp(key, "attn_lds_pad")) {
-        if (value < 0 || value > 48 * 1024) return fail("attn_lds_pad must be 0..49152");
-        g_attn_lds_pad = value;
-        return 0;
-    }
-    if (!strcmp(key, "x3_pack_cache")) {
-        g_x3_pack_cache = value != 0;
-        return 0;
-    }
-    if (!strcmp(key, "gemm_x3_mode")) {
-        if (value < 0 || value > 1) return fail("gemm_x3_mode must be 0..1");
-        g_gemm_x3_mode = value;
-        return 0;
-    }
-    if (!strcmp(key, "gemm16_probe")) {
-        if (value < 0 || value > 6) return fail("gemm16_probe must be 0..6");
-        g_gemm16_probe = value;
-        return 0;
-    }
-    return fail(std::string("s3enc_set_tuning: unknown key '") + key + "'");
-}
-
-// ---- single-kernel entry points -------------------------------------------------------------------------------
-int s3enc_op_gemm(int32_t dtype, const void* A, int64_t lda, int64_t a_batch_stride, const void* W, const float* bias, int32_t M,
-                  int32_t N, int32_t K, int32_t batches, int32_t act, const float* residual, const int32_t* row_limit,
-                  float* out32, void* out16, int64_t ldo, int64_t o_batch_stride, void* stream) {
-    GemmParams g{};
-    g.A = A;
-    g.lda = lda;
-    g.a_bs = a_batch_stride;
-    g.W = W;
-    g.bias = bias;
-    g.M = M;
-    g.N = N;
-    g.K = K;
-    g.batches = batches;
-    g.act = act;
-    g.residual = residual;
-    g.row_limit = row_limit;
-    g.out32 = out32;
-    g.out16 = out16;
-    g.ldo = ldo;
-    g.o_bs = o_batch_stride;
-    if (dtype == 3) {  // S3ENC_F32X3: fp32 operands; W is split into its pair-packed bf16 hi / lo image here
-        if (K % 32) return fail("s3enc_op_gemm: S3ENC_F32X3 needs K % 32 == 0");
-        // tuning key "x3_pack_cache" (micro-benchmarks only): keep the packed image of the last (W, N, K) and skip the
-        // host round trip + synchronisation when the same weight pointer comes back
-        static DevBuf cached;
-        static const void* cached_w = nullptr;
-        static long cached_n = 0, cached_k = 0;
-        if (g_x3_pack_cache && cached_w == W && cached_n == N && cached_k == K) {
-            g.W_x3 = cached.p;
-            if (!gemm_x3_eligible(g)) return fail("s3enc_op_gemm: shape / alignment not eligible for the S3ENC_F32X3 kernel");
-            HIP_TRY(launch_gemm(F32, g, (hipStream_t)stream));
-            return 0;
-        }
-        std::vector<float> hw((size_t)N * K);
-        HIP_TRY(hipMemcpy(hw.data(), W, hw.size() * 4, hipMemcpyDeviceToHost));
-        DevBuf w3;
-        HIP_TRY(upload_x3(w3, hw, N, K));
-        g.W_x3 = w3.p;
-        if (!gemm_x3_eligible(g)) return fail("s3enc_op_gemm: shape / alignment not eligible for the S3ENC_F32X3 kernel");
-        HIP_TRY(launch_gemm(F32, g, (hipStream_t)stream));
-        HIP_TRY(hipStreamSynchronize((hipStream_t)stream));  // w3 is freed on return (or kept as the cache)
-        if (g_x3_pack_cache) {
-            HIP_TRY(hipDeviceSynchronize());
-            std::swap(cached.p, w3.p);
-            std::swap(cached.bytes, w3.bytes);
-            cached_w = W;
-            cached_n = N;
-            cached_k = K;
-        }
-        return 0;
-    }
-    HIP_TRY(launch_gemm(dtype, g, (hipStream_t)stream));
-    return 0;
-}
-
-int s3enc_op_layernorm(int32_t dtype, const float* x, const float* gamma, const float* beta, int32_t rows, int32_t C, int32_t act,
-                       float* out32, void* out16, void* stream) {
-    HIP_TRY(launch_layernorm(dtype, x, gamma, beta, rows, C, act, out32, out16, (hipStream_t)stream));
-    return 0;
-}
-
-int s3enc_op_attention(int32_t dtype, const void* qkv, void* out, const int32_t* valid, int32_t B, int32_t T, int32_t H,
-                       const float* bias_table, int32_t table_R, const float* gate, void* stream) {
-    if (bias_table && (table_R < 0 || T > 6000)) return fail("s3enc_op_attention: bad table_R / T > 6000 with a bias table");
-    AttnParams a{};
-    a.qkv = qkv;
-    a.out = out;
-    a.valid = valid;
-    a.B = B;
-    a.T = T;
-    a.H = H;
-    a.bias_table = bias_table;
-    a.table_R = table_R;
-    a.gate = gate;
-    HIP_TRY(launch_attention(dtype, a, (hipStream_t)stream));
-    return 0;
-}
-
-int s3enc_op_conv0(int32_t dtype, const float* const* wavs, const int64_t* lengths, int32_t B, int64_t n_max, int32_t normalize,
-                   const float* w0, const float* bias, const float* gn_gamma, const float* gn_beta, const float* ln_gamma,
-                   const float* ln_beta, int32_t C, int32_t stride, void* out, void* stream) {
-    if (!wavs || !lengths || !w0 || !out) return fail("s3enc_op_conv0: null argument");
-    if (B <= 0 || C <= 0 || (C % 32) || C > 1024 || stride <= 0) return fail("s3enc_op_conv0: bad shape");
-    if (dtype < 0 || dtype > 2) return fail("s3enc_op_conv0: dtype must be S3ENC_F32 / BF16 / F16");
-    if ((gn_gamma != nullptr) == (ln_gamma != nullptr)) return fail("s3enc_op_conv0: pass exactly one of gn_gamma / ln_gamma");
-    const int k0 = 10;
-    long nm = 0;
-    for (int b = 0; b < B; ++b) nm = lengths[b] > nm ? lengths[b] : nm;
-    if (n_max > 0 && n_max < nm) return fail("s3enc_op_conv0: n_max is smaller than the longest utterance");
-    if (n_max > 0) nm = n_max;
-    if (nm < k0) return fail("s3enc_op_conv0: input shorter than the kernel");
-    const long L0 = (nm - k0) / stride + 1;
-    hipStream_t st = (hipStream_t)stream;
-    // scratch: table (ptrs, lens), per-utterance norm, per-(b, c) GroupNorm affine, reduction partials
-    const size_t tbl = (size_t)B * 16, part = stats_partial_elems(B, nm);
-    DevBuf buf;
-    Bump sz(nullptr);
-    sz.take(tbl);
-    sz.take((size_t)B * sizeof(float2));
-    sz.take((size_t)B * C * sizeof(float2));
-    sz.take(part * 8);
-    HIP_TRY(buf.ensure(sz.off + 256));
-    Bump bb(buf.p);
-    char* d_tbl = (char*)bb.take(tbl);
-    float2* d_norm = (float2*)bb.take((size_t)B * sizeof(float2));
-    float2* d_gn = (float2*)bb.take((size_t)B * C * sizeof(float2));
-    double* d_part = (double*)bb.take(part * 8);
-    std::vector<char> host(tbl);
-    memcpy(host.data(), wavs, (size_t)B * 8);
-    for (int b = 0; b < B; ++b) ((long*)(host.data() + (size_t)B * 8))[b] = (long)lengths[b];
-    HIP_TRY(hipMemcpy(d_tbl, host.data(), tbl, hipMemcpyHostToDevice));
-    WavTable wt{(const float* const*)d_tbl, (const long*)(d_tbl + (size_t)B * 8), B, nm};
-    HIP_TRY(launch_wav_norm_stats(wt, normalize, d_part, d_norm, st));
-    if (gn_gamma) HIP_TRY(launch_gn_stats(wt, d_norm, w0, gn_gamma, gn_beta, C, k0, stride, L0, d_part, nullptr, d_gn, st));
-    Conv0Params p{};
-    p.wav = wt;
-    p.norm = d_norm;
-    p.w0 = w0;
-    p.bias = bias;
-    p.gn = gn_gamma ? d_gn : nullptr;
-    p.ln_g = ln_gamma;
-    p.ln_b = ln_beta;
-    p.C = C;
-    p.k0 = k0;
-    p.s0 = stride;
-    p.L0 = L0;
-    p.out = out;
-    HIP_TRY(launch_conv0(dtype, p, st));
-    HIP_TRY(hipStreamSynchronize(st));  // the scratch is freed on return
-    return 0;
-}
-
-int s3enc_op_wavlm_gate(const float* x, const float* grep_w, const float* grep_b, const float* grep_a, int32_t B, int32_t T,
-                        int32_t H, float* gate, void* stream) {
-    if (!x || !grep_w || !grep_b || !grep_a || !gate) return fail("s3enc_op_wavlm_gate: null argument");
-    if (B <= 0 || T <= 0 || H <= 0) return fail("s3enc_op_wavlm_gate: bad shape");
-    HIP_TRY(launch_wavlm_gate(x, grep_w, grep_b, grep_a, B, T, H, gate, (hipStream_t)stream));
-    return 0;
-}
-
-int s3enc_op_posconv(int32_t dtype, const float* x, const float* w_host, const float* bias, int32_t B, int32_t T, int32_t D,
-                     int32_t G, int32_t K, float* out, void* stream) {
-    if (!x || !w_host || !bias || !out) return fail("s3enc_op_posconv: null argument");
-    if (G <= 0 || D % G) return fail("s3enc_op_posconv: D must be a multiple of groups");
-    const int Dg = D / G;
-    std::vector<float> w(w_host, w_host + (size_t)D * Dg * K), packed;
-    DevBuf dw;
-    if (dtype == 3) {
-        HIP_TRY(upload_posconv_x3(dw, w, D, G, K));
-    } else {
-        pack_posconv(w, D, G, K, dtype, packed);
-        HIP_TRY(upload_cvt(dw, packed, dtype));
-    }
-    PosConvParams p{};
-    p.x = x;
-    p.w = dw.p;
-    p.bias = bias;
-    p.out = out;
-    p.B = B;
-    p.T = T;
-    p.D = D;
-    p.G = G;
-    p.K = K;
-    HIP_TRY(dtype == F32 ? launch_posconv(p, (hipStream_t)stream) : launch_posconv16(dtype, p, (hipStream_t)stream));
-    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));  // the packed weights are freed on return
-    return 0;
-}
-
-int s3enc_weighted_sum(const float* hs, int64_t layer_stride, int32_t L, const float* w, int32_t normalize, int64_t rows, int32_t D,
-                       float* out, void* stream) {
-    if (!hs || !w || !out) return fail("s3enc_weighted_sum: null argument");
-    if (L <= 0 || L > S3_WS_MAX_LAYERS) return fail("s3enc_weighted_sum: 1..32 layers");
-    if (D <= 0 || (D & 3) || D > 2048) return fail("s3enc_weighted_sum: D must be a multiple of 4, <= 2048");
-    HIP_TRY(launch_weighted_sum(hs, layer_stride, L, w, normalize, rows, D, out, (hipStream_t)stream));
-    return 0;
-}
-
-int64_t s3enc_weighted_sum_backward_scratch(int64_t rows, int32_t L) {
-    return rows > 0 && L > 0 ? (int64_t)weighted_sum_bwd_blocks(rows) * L : 0;
-}
-
-int s3enc_weighted_sum_backward(const float* hs, int64_t layer_stride, int32_t L, int32_t normalize, int64_t rows, int32_t D,
-                                const float* grad_out, float* grad_w, double* scratch, void* stream) {
-    if (!hs || !grad_out || !grad_w || !scratch) return fail("s3enc_weighted_sum_backward: null argument");
-    if (L <= 0 || L > S3_WS_MAX_LAYERS) return fail("s3enc_weighted_sum_backward: 1..32 layers");
-    if (D <= 0 || (D & 3) || D > 2048) return fail("s3enc_weighted_sum_backward: D must be a multiple of 4, <= 2048");
-    if (rows <= 0) return fail("s3enc_weighted_sum_backward: no rows");
-    HIP_TRY(launch_weighted_sum_bwd(hs, layer_stride, L, normalize, rows, D, grad_out, scratch, grad_w, (hipStream_t)stream));
-    return 0;
-}
-
-static FbankParams fbank_params(const s3enc_fbank_config* c) {
-    FbankParams f;
-    f.sample_rate = c->sample_rate;
-    f.num_mel_bins = c->num_mel_bins;
-    f.frame_length_ms = c->frame_length_ms;
-    f.frame_shift_ms = c->frame_shift_ms;
-    f.preemph = c->preemphasis;
-    f.delta_order = c->delta_order;
-    f.delta_win = c->delta_win_length;
-    f.use_cmvn = c->use_cmvn;
-    f.cmvn_eps = c->cmvn_eps;
-    return f;
-}
-
-int s3enc_fbank_num_frames(const s3enc_fbank_config* cfg, int64_t n_samples, int32_t* frames) {
-    if (!cfg || !frames) return fail("s3enc_fbank_num_frames: null argument");
-    *frames = (int32_t)fbank_num_frames(n_samples, fbank_params(cfg));
-    return 0;
-}
-
-int s3enc_fbank_forward(const s3enc_fbank_config* cfg, const float* const* wavs, const int64_t* lengths, int32_t B, float* out,
-                        int64_t T_max, int32_t device, void* stream) {
-    if (!cfg || !wavs || !lengths || !out) return fail("s3enc_fbank_forward: null argument");
-    if (B <= 0) return fail("s3enc_fbank_forward: empty batch");
-    const FbankParams f = fbank_params(cfg);
-    if (f.delta_order < 0 || f.delta_order > 2 || f.delta_win < 3 || !(f.delta_win & 1)) return fail("s3enc_fbank_forward: unsupported delta configuration");
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail("s3enc_fbank_forward: no HIP device (there is no CPU fallback)");
-    HIP_TRY(hipSetDevice(device));
-    const int F = f.num_mel_bins * (f.delta_order + 1);
-    hipStream_t st = (hipStream_t)stream;
-    HIP_TRY(hipMemsetAsync(out, 0, (size_t)B * T_max * F * sizeof(float), st));
-    for (int b = 0; b < B; ++b) {
-        const long T = fbank_num_frames(lengths[b], f);
-        if (T <= 0) return fail("s3enc_fbank_forward: an utterance is shorter than one analysis window");
-        if (T > T_max) return fail("s3enc_fbank_forward: T_max is smaller than an utterance's frame count");
-        HIP_TRY(launch_fbank(f, wavs[b], lengths[b], out + (size_t)b * T_max * F, F, st));
-    }
-    return 0;
-}
-
 }  // extern "C"

@@ -1,0 +1,419 @@
+// engine_internal.h — what the translation units of the engine share: error reporting, device buffers, the weight containers,
+// the handle (struct s3enc_encoder), per-kernel profiling, the workspace allocator and the multires-HuBERT plan.
+//   engine.hip    s3enc_create (weight packing), the single-resolution forward schedule, graph replay, the handle's C ABI
+//   multires.hip  the multires-HuBERT U-net behind post_extract_proj
+//   ops.hip       single-kernel entry points (s3enc_op_*), the weighted sum, fbank, tuning keys
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/s3enc.h"
+#include "kernels.h"
+
+namespace s3e {
+using namespace s3;
+
+
+extern thread_local std::string g_err;  // s3enc_last_error()
+extern int g_x3_pack_cache;
+
+inline int fail(const std::string& msg) {
+    g_err = msg;
+    return 1;
+}
+
+#define HIP_TRY(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess) {                                                                        \
+            char _b[512];                                                                              \
+            snprintf(_b, sizeof(_b), "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return fail(_b);                                                                           \
+        }                                                                                              \
+    } while (0)
+
+// ---- host-side dtype conversion -------------------------------------------------------------------------
+inline uint16_t h_bf16(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+inline uint16_t h_f16(float f) {
+    _Float16 h = (_Float16)f;
+    uint16_t r;
+    memcpy(&r, &h, 2);
+    return r;
+}
+inline float h_from16(uint16_t v, int dtype) {
+    if (dtype == BF16) {
+        uint32_t u = ((uint32_t)v) << 16;
+        float f;
+        memcpy(&f, &u, 4);
+        return f;
+    }
+    _Float16 h;
+    memcpy(&h, &v, 2);
+    return (float)h;
+}
+
+// bumped by every (re)allocation of a DevBuf: a captured forward graph bakes workspace addresses in, so a graph made
+// under an older generation is discarded and re-captured (s3enc_set_graph_replay)
+extern unsigned long g_devbuf_gen;
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes) {
+        o.p = nullptr;
+        o.bytes = 0;
+    }
+    hipError_t ensure(size_t n) {
+        if (n <= bytes) return hipSuccess;
+        if (p) {
+            hipError_t e = hipFree(p);  // implicit device sync: nothing in flight still uses it
+            p = nullptr;
+            bytes = 0;
+            if (e != hipSuccess) return e;
+        }
+        hipError_t e = hipMalloc(&p, n);
+        if (e == hipSuccess) bytes = n;
+        ++g_devbuf_gen;
+        return e;
+    }
+    // Growth on the forward path, ordered on `st` instead of synchronising the device: the old block is released with
+    // hipFreeAsync (it may still be read by launches already enqueued on `st`) and the new one comes from the
+    // stream-ordered allocator, 25 % larger than asked so a serving loop with drifting batch shapes settles after a few
+    // growths.  Falls back to the synchronising path if the runtime has no stream-ordered pool.
+    hipError_t ensure_on_stream(size_t n, hipStream_t st) {
+        if (n <= bytes) return hipSuccess;
+        const size_t want = n + n / 4;
+        void* np = nullptr;
+        hipError_t e = hipMallocAsync(&np, want, st);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return ensure(want);
+        }
+        if (p) {
+            e = hipFreeAsync(p, st);
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                (void)hipStreamSynchronize(st);
+                (void)hipFree(p);
+            }
+        }
+        p = np;
+        bytes = want;
+        ++g_devbuf_gen;
+        return hipSuccess;
+    }
+};
+
+// current-device RAII: the entry points never leave the caller's (torch's) current device changed
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        int cur = -1;
+        if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+    }
+};
+
+inline hipError_t upload_f32(DevBuf& d, const std::vector<float>& v) {
+    hipError_t e = d.ensure(v.size() * 4 + 16);
+    if (e != hipSuccess) return e;
+    return hipMemcpy(d.p, v.data(), v.size() * 4, hipMemcpyHostToDevice);
+}
+inline hipError_t upload_cvt(DevBuf& d, const std::vector<float>& v, int dtype) {
+    if (dtype == F32) return upload_f32(d, v);
+    std::vector<uint16_t> h(v.size());
+    if (dtype == BF16)
+        for (size_t i = 0; i < v.size(); ++i) h[i] = h_bf16(v[i]);
+    else
+        for (size_t i = 0; i < v.size(); ++i) h[i] = h_f16(v[i]);
+    hipError_t e = d.ensure(h.size() * 2 + 16);
+    if (e != hipSuccess) return e;
+    return hipMemcpy(d.p, h.data(), h.size() * 2, hipMemcpyHostToDevice);
+}
+
+// Positional-conv weight (folded, [D][Dg][K] like nn.Conv1d.weight) -> the layout of the kernel of `dtype`:
+//   fp32   [G][K][Dg/16][Dg(co)][16]         (posconv_kernel: tap-major 16-deep input-channel chunks)
+//   16-bit [G][Dg(co)][k = tap*Dg + ci]       (posconv16_kernel: the W operand of the implicit GEMM)
+inline void pack_posconv(const std::vector<float>& w, int D, int G, int K, int dtype, std::vector<float>& out) {
+    const int Dg = D / G;
+    out.assign((size_t)G * K * Dg * Dg, 0.f);
+    for (int gi = 0; gi < G; ++gi)
+        for (int n = 0; n < Dg; ++n)
+            for (int ci = 0; ci < Dg; ++ci)
+                for (int k = 0; k < K; ++k) {
+                    const float x = w[((long)(gi * Dg + n) * Dg + ci) * K + k];
+                    if (dtype == F32)
+                        out[((((long)gi * K + k) * (Dg / 16) + ci / 16) * Dg + n) * 16 + ci % 16] = x;
+                    else
+                        out[(((long)gi * Dg + n) * K + k) * Dg + ci] = x;
+                }
+}
+
+// S3ENC_F32X3: upload the pair-packed bf16 hi / lo image of an (N, K) fp32 weight (K % 32 == 0, else left empty: that
+// GEMM then runs on the exact kernel)
+inline hipError_t upload_x3(DevBuf& d, const std::vector<float>& v, long N, long K) {
+    if (K % 32 || (long)v.size() < N * K) return hipSuccess;
+    std::vector<uint16_t> pk;
+    pack_x3(v.data(), N, K, pk);
+    hipError_t e = d.ensure(pk.size() * 2 + 16);
+    if (e != hipSuccess) return e;
+    return hipMemcpy(d.p, pk.data(), pk.size() * 2, hipMemcpyHostToDevice);
+}
+
+// S3ENC_F32X3 positional conv: the 16-bit layout [G][Dg][K*Dg] as a bf16 hi image followed by the lo image
+inline hipError_t upload_posconv_x3(DevBuf& d, const std::vector<float>& w, int D, int G, int K) {
+    std::vector<float> lay;
+    pack_posconv(w, D, G, K, BF16, lay);
+    std::vector<uint16_t> img(lay.size() * 2);
+    for (size_t i = 0; i < lay.size(); ++i) {
+        const uint16_t h = h_bf16(lay[i]);
+        img[i] = h;
+        img[lay.size() + i] = h_bf16(lay[i] - h_from16(h, BF16));
+    }
+    hipError_t e = d.ensure(img.size() * 2 + 16);
+    if (e != hipSuccess) return e;
+    return hipMemcpy(d.p, img.data(), img.size() * 2, hipMemcpyHostToDevice);
+}
+
+struct LayerW {
+    DevBuf wqkv, bqkv, wo, bo, ln1g, ln1b, w1, b1, w2, b2, ln2g, ln2b;
+    DevBuf wqkv3, wo3, w13, w23;  // S3ENC_F32X3: pair-packed bf16 hi / lo images of the four weight matrices
+    DevBuf grep_w, grep_b, grep_a;
+};
+struct ConvW {
+    DevBuf w, bias, lng, lnb;  // w: conv0 fp32 [C][k]; conv>=1 compute dtype [C][k*Cin]
+    DevBuf w3;                 // S3ENC_F32X3: pair-packed image of w (conv >= 1)
+    bool has_bias = false;
+};
+
+// multires-HuBERT (multires_hubert/hubert_model.py:337-530): one TransformerEncoder of the U-net, and a conv adapter
+struct BlockW {
+    std::vector<LayerW> layers;
+    DevBuf eln_g, eln_b;  // the block's own encoder.layer_norm
+};
+struct AdapterConvW {
+    DevBuf w, w3;  // the convolution as a GEMM operand (N, K) in the compute dtype (+ the S3ENC_F32X3 image)
+    DevBuf g, b;   // Fp32GroupNorm(1, D) affine
+};
+struct AdapterW {
+    AdapterConvW up, down;  // ConvTranspose1d(stride = up_rate) / Conv1d(stride = down_rate); plain variants hold one
+    int kind = 0;           // 0 ConvAdapter (both), 1 ConvDownsampler, 2 ConvUpsampler
+    int up_rate = 1, down_rate = 1;
+};
+
+struct ProfRec {
+    int kind;
+    hipEvent_t a, b;
+};
+
+}  // namespace s3e
+
+using namespace s3e;  // (internal header: only the engine's own translation units include it)
+
+struct s3enc_encoder {
+    // (the names below are s3e:: / s3:: types)
+    s3enc_config cfg;
+    int device = 0;
+    int dtype = F32;
+    bool x3 = false;  // S3ENC_F32X3
+    int es = 4;  // element size of the compute dtype
+    std::vector<ConvW> conv;
+    DevBuf gn_g, gn_b;
+    DevBuf fln_g, fln_b, proj_w, proj_b, pos_w, pos_b, eln_g, eln_b;
+    DevBuf proj_w3, pos_w3;  // S3ENC_F32X3
+    std::vector<LayerW> layers;
+    DevBuf rel_table;  // WavLM: [H][2R+1], entry (h, rel + R), R = max_distance (the bucket saturates there)
+    int rel_R = 0;
+    // data2vec positional-conv stack (cfg.pos_conv_depth > 1): per block the packed conv weight + bias; pos_k = the kernel
+    // width as packed (zero taps appended so that the 16-bit implicit GEMM's k axis is a multiple of 128), pos_pad = the
+    // real kernel's K / 2; ones / zeros = the affine of LayerNorm(elementwise_affine=False)
+    std::vector<DevBuf> pos_ws, pos_bs;
+    int pos_k = 0, pos_pad = 0;
+    DevBuf ones, zeros;
+    DevBuf head_w1, head_b1, head_w2, head_b2, head_w13, head_w23;  // DistilHuBERT prediction heads (+ S3ENC_F32X3 images)
+    DevBuf wsum_part;  // persistent partials of s3enc_weighted_sum_backward
+    std::vector<BlockW> mr_blocks;      // S3ENC_MULTIRES: encoders..., middle_encoder, decoders... (execution order)
+    std::vector<AdapterW> mr_adapters;  // downsample_modules[0..R-2], then upsample_modules[0..R-2]
+    DevBuf ws_mr;                       // activation workspace of the U-net behind post_extract_proj
+
+    // hipGraph replay of repeated forwards (s3enc_set_graph_replay): one executable graph per (batch shape, state
+    // selection, output block).  The per-call data — waveform pointers, lengths, valid frames — reach the kernels through
+    // the device table that is uploaded BEFORE the graph is launched, so a replay is: table upload + one hipGraphLaunch.
+    struct GraphSlot {
+        int B = 0;
+        long n_max = 0;
+        int selection = 0, out_dtype = 0;
+        const void* out = nullptr;
+        long stride = 0;
+        hipGraphExec_t exec = nullptr;
+        unsigned long gen = 0;  // g_devbuf_gen the graph was captured under
+        int seen = 0;           // successful eager forwards with this key (the first one sizes workspaces and LDS attributes)
+        unsigned long used = 0;
+    };
+    int graphs_on = 0;
+    std::vector<GraphSlot> graphs;
+    unsigned long graph_clock = 0;
+    long graph_replays = 0, graph_captures = 0;
+    bool capture_aborted = false;
+    // the NULL (legacy default) stream cannot be captured: with graph replay on, a forward submitted to it runs on this
+    // private stream instead, fenced by events on both sides (ordered after the caller's earlier work, before its later work)
+    hipStream_t graph_stream = nullptr;
+    hipEvent_t graph_ev_in = nullptr, graph_ev_out = nullptr;
+
+    DevBuf ws;      // activation workspace
+    DevBuf small;   // tables, stats
+    void* pinned = nullptr;  // host staging ring
+    static constexpr int RING = 4;
+    size_t slot_bytes = 0;
+    hipEvent_t slot_ev[RING] = {};
+    int slot_next = 0;
+
+    std::vector<hipEvent_t> layer_events;  // caller-owned, recorded when hidden_states[l] is final
+
+    // profiling
+    int prof = 0;  // 0 off, 1 every kernel, 2 only the GEMM launches (the dominant kernel: cheap enough for a timed region)
+    std::vector<std::string> kinds;
+    std::vector<double> kflops, kbytes;
+    std::vector<long> klaunches;
+    std::vector<ProfRec> recs;
+    std::vector<hipEvent_t> ev_pool;  // timing events are recycled across profile_reset, never created per forward twice
+
+    // debug taps of the last forward
+    struct Tap {
+        const void* p;
+        long elems;
+        int dtype;
+    };
+    std::map<std::string, Tap> taps;
+
+    ~s3enc_encoder() {
+        for (auto& r : recs) {
+            (void)hipEventDestroy(r.a);
+            (void)hipEventDestroy(r.b);
+        }
+        for (auto ev : ev_pool) (void)hipEventDestroy(ev);
+        for (auto& g : graphs)
+            if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        if (graph_ev_in) (void)hipEventDestroy(graph_ev_in);
+        if (graph_ev_out) (void)hipEventDestroy(graph_ev_out);
+        if (graph_stream) (void)hipStreamDestroy(graph_stream);
+        for (int i = 0; i < RING; ++i)
+            if (slot_ev[i]) (void)hipEventDestroy(slot_ev[i]);
+        if (pinned) (void)hipHostFree(pinned);
+    }
+
+    int kind_id(const char* name) {
+        for (size_t i = 0; i < kinds.size(); ++i)
+            if (kinds[i] == name) return (int)i;
+        kinds.push_back(name);
+        kflops.push_back(0);
+        kbytes.push_back(0);
+        klaunches.push_back(0);
+        return (int)kinds.size() - 1;
+    }
+    bool take_event(hipEvent_t* ev) {
+        if (!ev_pool.empty()) {
+            *ev = ev_pool.back();
+            ev_pool.pop_back();
+            return true;
+        }
+        return hipEventCreate(ev) == hipSuccess;
+    }
+};
+
+namespace s3e {
+
+struct Prof {
+    s3enc_encoder* e;
+    hipStream_t st;
+    int idx = -1;
+    Prof(s3enc_encoder* enc, hipStream_t s, const char* kind, double flops, double bytes) : e(enc), st(s) {
+        if (!e || !e->prof) return;
+        if (e->prof == 2 && strncmp(kind, "gemm", 4) != 0) return;
+        const int k = e->kind_id(kind);
+        e->kflops[k] += flops;
+        e->kbytes[k] += bytes;
+        e->klaunches[k] += 1;
+        ProfRec r;
+        r.kind = k;
+        if (!e->take_event(&r.a)) return;
+        if (!e->take_event(&r.b)) {
+            e->ev_pool.push_back(r.a);
+            return;
+        }
+        (void)hipEventRecord(r.a, st);
+        e->recs.push_back(r);
+        idx = (int)e->recs.size() - 1;
+    }
+    ~Prof() {
+        if (idx >= 0) (void)hipEventRecord(e->recs[idx].b, st);
+    }
+};
+
+long conv_len(const s3enc_config& c, long n, int upto /*exclusive*/);  // frames after the first `upto` conv layers
+int valid_frames(const s3enc_config& c, long length, long n_max);      // un-masked frames under the family's mask rule
+
+// ---- multires-HuBERT frame geometry (mirrors EncoderConfig.multires_plan in s3prl_amd/config.py) ----------------
+struct MrBlockPlan {
+    int layers;
+    long T;       // frames the block runs on
+    int factor;   // repeat_interleave factor of its states (multires_hubert/expert.py:41-47)
+    int adapter;  // index into mr_adapters of the conv adapter applied before the block, -1 for the first
+    long T_in;    // frames entering that adapter
+    long T_sum;   // decoders: min(T, residual frames) of align_size_sum (hubert_model.py:777-783)
+};
+struct MrPlan {
+    std::vector<MrBlockPlan> blocks;
+    long T_out = 0;  // common length every (repeated) state is cut to (expert.py:93-101)
+};
+void mr_plan(const s3enc_config& c, long T0, MrPlan& plan);
+long output_frames(const s3enc_config& c, long n_samples);  // frames of the states a forward writes
+
+// bump allocator over the workspace
+struct Bump {
+    char* base;
+    size_t off = 0;
+    explicit Bump(void* b) : base((char*)b) {}
+    void* take(size_t bytes) {
+        void* p = base ? base + off : nullptr;
+        off += (bytes + 255) & ~(size_t)255;
+        return p;
+    }
+};
+
+struct FwdOpts {
+    int selection = S3ENC_SEL_HIDDEN;
+    int out_dtype = F32;
+    bool featurize = false;
+    int feat_norm = 0;
+    const float* w = nullptr;  // host, one per state
+};
+int num_states(const s3enc_config& c, int selection);
+// multires.hip: the U-net behind post_extract_proj (xproj: (B, T0, D) fp32, padded frames zero)
+int multires_tail(s3enc_handle e, hipStream_t st, int B, const MrPlan& plan, const std::vector<const int*>& d_valid, float* xproj,
+                  void* out, long layer_stride, const FwdOpts& fo);
+
+}  // namespace s3e

@@ -145,7 +145,7 @@ hipError_t launch_posconv16(int dtype, const PosConvParams& p, hipStream_t s);
 // ---- adapter.hip (multires-HuBERT: the row passes of the conv adapters, multires_hubert/hubert_model.py:970-1266) ------
 // Operand geometry of the adapter convolutions: per utterance `total` rows of D — `lead` zero rows, the data rows, zero
 // rows to the end — so that a Conv1d / ConvTranspose1d window that hangs over either end reads zeros and the convolution
-// is a plain GEMM over contiguous k*D-element rows (engine.hip).
+// is a plain GEMM over contiguous k*D-element rows (multires.hip; weights packed by load_conv in engine.hip).
 struct PadCopyParams {
     const float* a;      // (B, >= rows, D) fp32, utterance b at a + b*a_bs
     long a_bs;

@@ -1,0 +1,274 @@
+// ops.hip — the library-level entry points that are not tied to a handle: tuning keys, the single-kernel entry points the
+// op-level tests and micro-benchmarks call (s3enc_op_*), the Featurizer's weighted sum and the fbank upstream.
+#include "engine_internal.h"
+
+extern "C" {
+
+int s3enc_set_tuning(const char* key, int32_t value) {
+    if (!key) return fail("s3enc_set_tuning: null key");
+    if (!strcmp(key, "gemm_variant")) {
+        if (value < 0 || value > 63) return fail("gemm_variant must be 0..63");
+        g_gemm_variant = value;
+        return 0;
+    }
+    if (!strcmp(key, "gemm16_big")) {
+        if (value < 0 || value > 9) return fail("gemm16_big must be 0..9");
+        g_gemm16_big = value;
+        return 0;
+    }
+    if (!strcmp(key, "attn_lds_pad")) {
+        if (value < 0 || value > 48 * 1024) return fail("attn_lds_pad must be 0..49152");
+        g_attn_lds_pad = value;
+        return 0;
+    }
+    if (!strcmp(key, "x3_pack_cache")) {
+        g_x3_pack_cache = value != 0;
+        return 0;
+    }
+    if (!strcmp(key, "gemm_x3_mode")) {
+        if (value < 0 || value > 1) return fail("gemm_x3_mode must be 0..1");
+        g_gemm_x3_mode = value;
+        return 0;
+    }
+    if (!strcmp(key, "gemm16_probe")) {
+        if (value < 0 || value > 6) return fail("gemm16_probe must be 0..6");
+        g_gemm16_probe = value;
+        return 0;
+    }
+    return fail(std::string("s3enc_set_tuning: unknown key '") + key + "'");
+}
+
+// ---- single-kernel entry points -------------------------------------------------------------------------------
+int s3enc_op_gemm(int32_t dtype, const void* A, int64_t lda, int64_t a_batch_stride, const void* W, const float* bias, int32_t M,
+                  int32_t N, int32_t K, int32_t batches, int32_t act, const float* residual, const int32_t* row_limit,
+                  float* out32, void* out16, int64_t ldo, int64_t o_batch_stride, void* stream) {
+    GemmParams g{};
+    g.A = A;
+    g.lda = lda;
+    g.a_bs = a_batch_stride;
+    g.W = W;
+    g.bias = bias;
+    g.M = M;
+    g.N = N;
+    g.K = K;
+    g.batches = batches;
+    g.act = act;
+    g.residual = residual;
+    g.row_limit = row_limit;
+    g.out32 = out32;
+    g.out16 = out16;
+    g.ldo = ldo;
+    g.o_bs = o_batch_stride;
+    if (dtype == 3) {  // S3ENC_F32X3: fp32 operands; W is split into its pair-packed bf16 hi / lo image here
+        if (K % 32) return fail("s3enc_op_gemm: S3ENC_F32X3 needs K % 32 == 0");
+        // tuning key "x3_pack_cache" (micro-benchmarks only): keep the packed image of the last (W, N, K) and skip the
+        // host round trip + synchronisation when the same weight pointer comes back
+        static DevBuf cached;
+        static const void* cached_w = nullptr;
+        static long cached_n = 0, cached_k = 0;
+        if (g_x3_pack_cache && cached_w == W && cached_n == N && cached_k == K) {
+            g.W_x3 = cached.p;
+            if (!gemm_x3_eligible(g)) return fail("s3enc_op_gemm: shape / alignment not eligible for the S3ENC_F32X3 kernel");
+            HIP_TRY(launch_gemm(F32, g, (hipStream_t)stream));
+            return 0;
+        }
+        std::vector<float> hw((size_t)N * K);
+        HIP_TRY(hipMemcpy(hw.data(), W, hw.size() * 4, hipMemcpyDeviceToHost));
+        DevBuf w3;
+        HIP_TRY(upload_x3(w3, hw, N, K));
+        g.W_x3 = w3.p;
+        if (!gemm_x3_eligible(g)) return fail("s3enc_op_gemm: shape / alignment not eligible for the S3ENC_F32X3 kernel");
+        HIP_TRY(launch_gemm(F32, g, (hipStream_t)stream));
+        HIP_TRY(hipStreamSynchronize((hipStream_t)stream));  // w3 is freed on return (or kept as the cache)
+        if (g_x3_pack_cache) {
+            HIP_TRY(hipDeviceSynchronize());
+            std::swap(cached.p, w3.p);
+            std::swap(cached.bytes, w3.bytes);
+            cached_w = W;
+            cached_n = N;
+            cached_k = K;
+        }
+        return 0;
+    }
+    HIP_TRY(launch_gemm(dtype, g, (hipStream_t)stream));
+    return 0;
+}
+
+int s3enc_op_layernorm(int32_t dtype, const float* x, const float* gamma, const float* beta, int32_t rows, int32_t C, int32_t act,
+                       float* out32, void* out16, void* stream) {
+    HIP_TRY(launch_layernorm(dtype, x, gamma, beta, rows, C, act, out32, out16, (hipStream_t)stream));
+    return 0;
+}
+
+int s3enc_op_attention(int32_t dtype, const void* qkv, void* out, const int32_t* valid, int32_t B, int32_t T, int32_t H,
+                       const float* bias_table, int32_t table_R, const float* gate, void* stream) {
+    if (bias_table && (table_R < 0 || T > 6000)) return fail("s3enc_op_attention: bad table_R / T > 6000 with a bias table");
+    AttnParams a{};
+    a.qkv = qkv;
+    a.out = out;
+    a.valid = valid;
+    a.B = B;
+    a.T = T;
+    a.H = H;
+    a.bias_table = bias_table;
+    a.table_R = table_R;
+    a.gate = gate;
+    HIP_TRY(launch_attention(dtype, a, (hipStream_t)stream));
+    return 0;
+}
+
+int s3enc_op_conv0(int32_t dtype, const float* const* wavs, const int64_t* lengths, int32_t B, int64_t n_max, int32_t normalize,
+                   const float* w0, const float* bias, const float* gn_gamma, const float* gn_beta, const float* ln_gamma,
+                   const float* ln_beta, int32_t C, int32_t stride, void* out, void* stream) {
+    if (!wavs || !lengths || !w0 || !out) return fail("s3enc_op_conv0: null argument");
+    if (B <= 0 || C <= 0 || (C % 32) || C > 1024 || stride <= 0) return fail("s3enc_op_conv0: bad shape");
+    if (dtype < 0 || dtype > 2) return fail("s3enc_op_conv0: dtype must be S3ENC_F32 / BF16 / F16");
+    if ((gn_gamma != nullptr) == (ln_gamma != nullptr)) return fail("s3enc_op_conv0: pass exactly one of gn_gamma / ln_gamma");
+    const int k0 = 10;
+    long nm = 0;
+    for (int b = 0; b < B; ++b) nm = lengths[b] > nm ? lengths[b] : nm;
+    if (n_max > 0 && n_max < nm) return fail("s3enc_op_conv0: n_max is smaller than the longest utterance");
+    if (n_max > 0) nm = n_max;
+    if (nm < k0) return fail("s3enc_op_conv0: input shorter than the kernel");
+    const long L0 = (nm - k0) / stride + 1;
+    hipStream_t st = (hipStream_t)stream;
+    // scratch: table (ptrs, lens), per-utterance norm, per-(b, c) GroupNorm affine, reduction partials
+    const size_t tbl = (size_t)B * 16, part = stats_partial_elems(B, nm);
+    DevBuf buf;
+    Bump sz(nullptr);
+    sz.take(tbl);
+    sz.take((size_t)B * sizeof(float2));
+    sz.take((size_t)B * C * sizeof(float2));
+    sz.take(part * 8);
+    HIP_TRY(buf.ensure(sz.off + 256));
+    Bump bb(buf.p);
+    char* d_tbl = (char*)bb.take(tbl);
+    float2* d_norm = (float2*)bb.take((size_t)B * sizeof(float2));
+    float2* d_gn = (float2*)bb.take((size_t)B * C * sizeof(float2));
+    double* d_part = (double*)bb.take(part * 8);
+    std::vector<char> host(tbl);
+    memcpy(host.data(), wavs, (size_t)B * 8);
+    for (int b = 0; b < B; ++b) ((long*)(host.data() + (size_t)B * 8))[b] = (long)lengths[b];
+    HIP_TRY(hipMemcpy(d_tbl, host.data(), tbl, hipMemcpyHostToDevice));
+    WavTable wt{(const float* const*)d_tbl, (const long*)(d_tbl + (size_t)B * 8), B, nm};
+    HIP_TRY(launch_wav_norm_stats(wt, normalize, d_part, d_norm, st));
+    if (gn_gamma) HIP_TRY(launch_gn_stats(wt, d_norm, w0, gn_gamma, gn_beta, C, k0, stride, L0, d_part, nullptr, d_gn, st));
+    Conv0Params p{};
+    p.wav = wt;
+    p.norm = d_norm;
+    p.w0 = w0;
+    p.bias = bias;
+    p.gn = gn_gamma ? d_gn : nullptr;
+    p.ln_g = ln_gamma;
+    p.ln_b = ln_beta;
+    p.C = C;
+    p.k0 = k0;
+    p.s0 = stride;
+    p.L0 = L0;
+    p.out = out;
+    HIP_TRY(launch_conv0(dtype, p, st));
+    HIP_TRY(hipStreamSynchronize(st));  // the scratch is freed on return
+    return 0;
+}
+
+int s3enc_op_wavlm_gate(const float* x, const float* grep_w, const float* grep_b, const float* grep_a, int32_t B, int32_t T,
+                        int32_t H, float* gate, void* stream) {
+    if (!x || !grep_w || !grep_b || !grep_a || !gate) return fail("s3enc_op_wavlm_gate: null argument");
+    if (B <= 0 || T <= 0 || H <= 0) return fail("s3enc_op_wavlm_gate: bad shape");
+    HIP_TRY(launch_wavlm_gate(x, grep_w, grep_b, grep_a, B, T, H, gate, (hipStream_t)stream));
+    return 0;
+}
+
+int s3enc_op_posconv(int32_t dtype, const float* x, const float* w_host, const float* bias, int32_t B, int32_t T, int32_t D,
+                     int32_t G, int32_t K, float* out, void* stream) {
+    if (!x || !w_host || !bias || !out) return fail("s3enc_op_posconv: null argument");
+    if (G <= 0 || D % G) return fail("s3enc_op_posconv: D must be a multiple of groups");
+    const int Dg = D / G;
+    std::vector<float> w(w_host, w_host + (size_t)D * Dg * K), packed;
+    DevBuf dw;
+    if (dtype == 3) {
+        HIP_TRY(upload_posconv_x3(dw, w, D, G, K));
+    } else {
+        pack_posconv(w, D, G, K, dtype, packed);
+        HIP_TRY(upload_cvt(dw, packed, dtype));
+    }
+    PosConvParams p{};
+    p.x = x;
+    p.w = dw.p;
+    p.bias = bias;
+    p.out = out;
+    p.B = B;
+    p.T = T;
+    p.D = D;
+    p.G = G;
+    p.K = K;
+    HIP_TRY(dtype == F32 ? launch_posconv(p, (hipStream_t)stream) : launch_posconv16(dtype, p, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));  // the packed weights are freed on return
+    return 0;
+}
+
+int s3enc_weighted_sum(const float* hs, int64_t layer_stride, int32_t L, const float* w, int32_t normalize, int64_t rows, int32_t D,
+                       float* out, void* stream) {
+    if (!hs || !w || !out) return fail("s3enc_weighted_sum: null argument");
+    if (L <= 0 || L > S3_WS_MAX_LAYERS) return fail("s3enc_weighted_sum: 1..32 layers");
+    if (D <= 0 || (D & 3) || D > 2048) return fail("s3enc_weighted_sum: D must be a multiple of 4, <= 2048");
+    HIP_TRY(launch_weighted_sum(hs, layer_stride, L, w, normalize, rows, D, out, (hipStream_t)stream));
+    return 0;
+}
+
+int64_t s3enc_weighted_sum_backward_scratch(int64_t rows, int32_t L) {
+    return rows > 0 && L > 0 ? (int64_t)weighted_sum_bwd_blocks(rows) * L : 0;
+}
+
+int s3enc_weighted_sum_backward(const float* hs, int64_t layer_stride, int32_t L, int32_t normalize, int64_t rows, int32_t D,
+                                const float* grad_out, float* grad_w, double* scratch, void* stream) {
+    if (!hs || !grad_out || !grad_w || !scratch) return fail("s3enc_weighted_sum_backward: null argument");
+    if (L <= 0 || L > S3_WS_MAX_LAYERS) return fail("s3enc_weighted_sum_backward: 1..32 layers");
+    if (D <= 0 || (D & 3) || D > 2048) return fail("s3enc_weighted_sum_backward: D must be a multiple of 4, <= 2048");
+    if (rows <= 0) return fail("s3enc_weighted_sum_backward: no rows");
+    HIP_TRY(launch_weighted_sum_bwd(hs, layer_stride, L, normalize, rows, D, grad_out, scratch, grad_w, (hipStream_t)stream));
+    return 0;
+}
+
+static FbankParams fbank_params(const s3enc_fbank_config* c) {
+    FbankParams f;
+    f.sample_rate = c->sample_rate;
+    f.num_mel_bins = c->num_mel_bins;
+    f.frame_length_ms = c->frame_length_ms;
+    f.frame_shift_ms = c->frame_shift_ms;
+    f.preemph = c->preemphasis;
+    f.delta_order = c->delta_order;
+    f.delta_win = c->delta_win_length;
+    f.use_cmvn = c->use_cmvn;
+    f.cmvn_eps = c->cmvn_eps;
+    return f;
+}
+
+int s3enc_fbank_num_frames(const s3enc_fbank_config* cfg, int64_t n_samples, int32_t* frames) {
+    if (!cfg || !frames) return fail("s3enc_fbank_num_frames: null argument");
+    *frames = (int32_t)fbank_num_frames(n_samples, fbank_params(cfg));
+    return 0;
+}
+
+int s3enc_fbank_forward(const s3enc_fbank_config* cfg, const float* const* wavs, const int64_t* lengths, int32_t B, float* out,
+                        int64_t T_max, int32_t device, void* stream) {
+    if (!cfg || !wavs || !lengths || !out) return fail("s3enc_fbank_forward: null argument");
+    if (B <= 0) return fail("s3enc_fbank_forward: empty batch");
+    const FbankParams f = fbank_params(cfg);
+    if (f.delta_order < 0 || f.delta_order > 2 || f.delta_win < 3 || !(f.delta_win & 1)) return fail("s3enc_fbank_forward: unsupported delta configuration");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail("s3enc_fbank_forward: no HIP device (there is no CPU fallback)");
+    HIP_TRY(hipSetDevice(device));
+    const int F = f.num_mel_bins * (f.delta_order + 1);
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(out, 0, (size_t)B * T_max * F * sizeof(float), st));
+    for (int b = 0; b < B; ++b) {
+        const long T = fbank_num_frames(lengths[b], f);
+        if (T <= 0) return fail("s3enc_fbank_forward: an utterance is shorter than one analysis window");
+        if (T > T_max) return fail("s3enc_fbank_forward: T_max is smaller than an utterance's frame count");
+        HIP_TRY(launch_fbank(f, wavs[b], lengths[b], out + (size_t)b * T_max * F, F, st));
+    }
+    return 0;
+}
+
+}  // extern "C"
