@@ -274,9 +274,22 @@ int s3enc_create(const s3enc_config* cfg, const s3enc_tensor* tensors, int32_t n
         for (int k = 0; k < K; ++k) nrm[k] = (double)g[k] / std::sqrt(nrm[k]);
         for (long i = 0; i < (long)D * Dg; ++i)
             for (int k = 0; k < K; ++k) v[i * K + k] = (float)(v[i * K + k] * nrm[k]);
-        pack_posconv(v, D, G, K, e->dtype, t2);
+        // the 16-bit / split-precision implicit GEMM wants an even tap count with K * Dg a multiple of 128: append zero
+        // taps (the real kernel keeps its K / 2 left padding), as for the data2vec stack above
+        int kp = K;
+        if (e->dtype != F32 || e->x3)
+            while ((kp & 1) || ((long)kp * Dg) % 128) ++kp;
+        e->pos_k = kp;
+        e->pos_pad = K / 2;
+        if (kp != K) {
+            std::vector<float> vp((size_t)D * Dg * kp, 0.f);
+            for (long r = 0; r < (long)D * Dg; ++r)
+                for (int j = 0; j < K; ++j) vp[r * kp + j] = v[r * K + j];
+            v.swap(vp);
+        }
+        pack_posconv(v, D, G, kp, e->dtype, t2);
         UP(upload_cvt(e->pos_w, t2, e->dtype));
-        if (e->x3) UP(upload_posconv_x3(e->pos_w3, v, D, G, K));
+        if (e->x3) UP(upload_posconv_x3(e->pos_w3, v, D, G, kp));
         GET(enc0 + ".pos_conv.0.bias", D, t);
         UP(upload_f32(e->pos_b, t));
     }
@@ -939,7 +952,8 @@ int forward_once(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
         p.T = (int)T;
         p.D = D;
         p.G = c.conv_pos_groups;
-        p.K = c.conv_pos;
+        p.K = e->pos_k;  // conv_pos, or conv_pos + zero taps in the 16-bit / fp32x3 modes
+        p.pad = e->pos_pad;
         auto run_conv = [&](PosConvParams& q) -> hipError_t {
             if (e->x3) return launch_posconv16(3, q, st);
             return dt == F32 ? launch_posconv(q, st) : launch_posconv16(dt, q, st);
@@ -969,7 +983,7 @@ int forward_once(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
             HIP_TRY(launch_add(xproj, (const float*)tmp2, pc_out, M * D, st));
             p.out = pc_out;
         } else {
-            Prof pr(e, st, "posconv", 2.0 * M * D * (D / p.G) * p.K, (double)M * D * 8 + (double)D * (D / p.G) * p.K * 4);
+            Prof pr(e, st, "posconv", 2.0 * M * D * (D / p.G) * c.conv_pos, (double)M * D * 8 + (double)D * (D / p.G) * c.conv_pos * 4);
             if (e->x3) p.w = e->pos_w3.p;
             HIP_TRY(run_conv(p));
         }

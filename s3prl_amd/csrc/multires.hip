@@ -178,8 +178,9 @@ int multires_tail(s3enc_handle e, hipStream_t st, int B, const MrPlan& plan, con
             p.T = (int)T;
             p.D = D;
             p.G = c.conv_pos_groups;
-            p.K = c.conv_pos;
-            Prof pr(e, st, "posconv", 2.0 * gM * D * (D / p.G) * p.K, gM * D * 8 + (double)D * (D / p.G) * p.K * 4);
+            p.K = e->pos_k;
+            p.pad = e->pos_pad;
+            Prof pr(e, st, "posconv", 2.0 * gM * D * (D / p.G) * c.conv_pos, gM * D * 8 + (double)D * (D / p.G) * p.K * 4);
             HIP_TRY(e->x3 ? launch_posconv16(3, p, st) : (dt == F32 ? launch_posconv(p, st) : launch_posconv16(dt, p, st)));
             cur = hA;
         }

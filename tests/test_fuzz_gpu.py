@@ -1,0 +1,103 @@
+"""Seeded sweep over architectures the C ABI accepts — widths, depths, conv stacks, positional-conv shapes, every family and
+norm placement, ragged batches — against the numpy oracle (fp32: the 1e-4 bar of the golden tests; bf16: finite and
+within its usual band).  The goldens pin the released architectures; this guards the generality the config struct promises."""
+
+import numpy as np
+import pytest
+
+from oracle import encoder_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _random_config(rng, medium=False):
+    from s3prl_amd.config import EncoderConfig
+
+    family = str(rng.choice(["hubert", "wav2vec2", "wavlm", "distiller", "multires_hubert"]))
+    heads = int(rng.choice([6, 8, 12] if medium else [1, 2, 3, 4]))
+    D = 64 * heads
+    groups = [g for g in (1, 2, 3, 4, 6, 8, 12, 16, 24) if D % g == 0 and D // g in (32, 48, 64)]
+    C = int(rng.choice([128, 256, 512] if medium else [32, 64, 96]))
+    n_mid = int(rng.integers(1, 5))
+    conv = [(C, 10, 5)] + [(C, int(rng.choice([2, 3])), int(rng.choice([1, 2]))) for _ in range(n_mid)] + [(C, 2, 2)]
+    kw = dict(family=family, conv_layers=conv, encoder_embed_dim=D, encoder_attention_heads=heads,
+              encoder_ffn_embed_dim=int(rng.choice([512, 1000, 1536] if medium else [64, 136, 256, 320])),
+              encoder_layers=int(rng.integers(1, 3 if medium else 4)),
+              conv_pos=int(rng.choice([3, 8, 15, 16, 31, 32])), conv_pos_groups=int(rng.choice(groups)),
+              layer_norm_first=bool(rng.integers(2)), extractor_mode=str(rng.choice(["default", "layer_norm"])),
+              conv_bias=bool(rng.integers(2)), normalize=bool(rng.integers(2)))
+    if family == "wavlm" and rng.integers(2):
+        kw.update(relative_position_embedding=True, num_buckets=int(rng.choice([16, 32, 64])), max_distance=int(rng.choice([40, 64, 128])),
+                  gru_rel_pos=bool(rng.integers(2)))
+    if family == "distiller":
+        kw.update(feature_layer_norm=False, pred_heads=int(rng.integers(1, 4)), normalize=False)
+    if family == "wav2vec2" and rng.integers(3) == 0:  # data2vec-audio positional stack
+        kw.update(pos_conv_depth=int(rng.integers(2, 5)), conv_pos=int(rng.choice([9, 15, 20])))
+    if family == "multires_hubert":
+        pairs = int(rng.integers(1, 3))
+        plain = bool(rng.integers(2))
+        blocks = [int(rng.integers(1, 3)) for _ in range(2 * pairs + 1)]
+        kw.update(label_rate_ratios=[1, 2] * pairs if plain else [int(x) for p in range(pairs) for x in ((1, 2) if rng.integers(2) else (2, 3))],
+                  block_layers=blocks, encoder_layers=sum(blocks), use_plain_updownsample=plain,
+                  conv_adapter_kernel=int(rng.choice([7, 13])) if not plain else 7)
+    cfg = EncoderConfig(**kw)
+    cfg.validate()
+    return cfg
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_architecture_matches_the_oracle(seed):
+    import torch
+
+    from s3prl_amd.encoder import HipEncoder
+    from s3prl_amd.synth import synth_wavs, synth_weights
+
+    rng = np.random.default_rng(1000 + seed)
+    cfg = _random_config(rng)
+    weights = synth_weights(cfg, seed)
+    rate = cfg.downsample_rate
+    B = int(rng.integers(1, 5))
+    lengths = [int(rng.integers(14 * rate, 40 * rate)) for _ in range(B)]
+    wavs = synth_wavs(lengths, seed + 1, dc=float(rng.choice([0.0, 0.2])), scale=float(rng.choice([1.0, 0.1])))
+    ref = O.forward(cfg, weights, wavs, dtype=np.float32)
+    dev = [torch.from_numpy(w).cuda() for w in wavs]
+    enc = HipEncoder(cfg, weights)
+    hs = enc.forward(dev).cpu().numpy()
+    assert hs.shape == (len(ref),) + ref[0].shape, (cfg, hs.shape, ref[0].shape)
+    errs = [O.rel_err(hs[l], ref[l]) for l in range(len(ref))]
+    assert max(errs) < 1e-4, (cfg, lengths, ["%.2e" % e for e in errs])
+    enc.close()
+    for dtype, tol in (("fp32x3", 1e-4), ("bf16", 6e-2)):
+        enc2 = HipEncoder(cfg, weights, dtype=dtype)
+        h2 = enc2.forward(dev).cpu().numpy()
+        assert np.isfinite(h2).all()
+        e2 = max(O.rel_err(h2[l], ref[l]) for l in range(len(ref)))
+        assert e2 < tol, (dtype, cfg, lengths, e2)
+        enc2.close()
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_medium_architecture_matches_the_oracle(seed):
+    """The same sweep at widths where the large-tile 16-bit GEMM, the three-wave LayerNorm rows and multi-tile attention
+    engage (D = 384..768, several hundred frames per batch)."""
+    import torch
+
+    from s3prl_amd.encoder import HipEncoder
+    from s3prl_amd.synth import synth_wavs, synth_weights
+
+    rng = np.random.default_rng(5000 + seed)
+    cfg = _random_config(rng, medium=True)
+    weights = synth_weights(cfg, seed)
+    rate = cfg.downsample_rate
+    B = int(rng.integers(2, 6))
+    lengths = [int(rng.integers(60 * rate, 160 * rate)) for _ in range(B)]
+    wavs = synth_wavs(lengths, seed + 1)
+    ref = O.forward(cfg, weights, wavs, dtype=np.float32)
+    dev = [torch.from_numpy(w).cuda() for w in wavs]
+    for dtype, tol in (("fp32", 1e-4), ("fp32x3", 1e-4), ("bf16", 6e-2), ("fp16", 8e-3)):
+        enc = HipEncoder(cfg, weights, dtype=dtype)
+        hs = enc.forward(dev).cpu().numpy()
+        assert hs.shape == (len(ref),) + ref[0].shape and np.isfinite(hs).all()
+        err = max(O.rel_err(hs[l], ref[l]) for l in range(len(ref)))
+        assert err < tol, (dtype, cfg, lengths, err)
+        enc.close()
