@@ -101,3 +101,58 @@ def test_random_medium_architecture_matches_the_oracle(seed):
         err = max(O.rel_err(hs[l], ref[l]) for l in range(len(ref)))
         assert err < tol, (dtype, cfg, lengths, err)
         enc.close()
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_forward_options_are_consistent(seed):
+    """The options of s3enc_forward_ex on random architectures: a padded-to-n_max shard against the oracle, the wav2vec2
+    feature selections, the featurize epilogue against the weighted sum of the states the same encoder writes, 16-bit state
+    output against the rounded fp32 output."""
+    import torch
+
+    from s3prl_amd.encoder import HipEncoder
+    from s3prl_amd.synth import synth_wavs, synth_weights
+
+    rng = np.random.default_rng(9000 + seed)
+    cfg = _random_config(rng)
+    weights = synth_weights(cfg, seed)
+    rate = cfg.downsample_rate
+    B = int(rng.integers(1, 5))
+    lengths = [int(rng.integers(14 * rate, 40 * rate)) for _ in range(B)]
+    n_max = max(lengths) + int(rng.integers(0, 6 * rate))
+    wavs = synth_wavs(lengths, seed + 1)
+    dev = [torch.from_numpy(w).cuda() for w in wavs]
+    selection = None
+    if cfg.family in ("hubert", "wav2vec2", "wavlm"):
+        selection = [None, "fairseq_layers", "fairseq_layers_before_residual"][int(rng.integers(3))]
+    ref = O.forward(cfg, weights, wavs, dtype=np.float32, n_max=n_max, selection=selection)
+    enc = HipEncoder(cfg, weights)
+    hs = enc.forward(dev, n_max=n_max, selection=selection)
+    got = hs.cpu().numpy()
+    assert got.shape == (len(ref),) + ref[0].shape
+    assert max(O.rel_err(got[l], ref[l]) for l in range(len(ref))) < 1e-4, (cfg, lengths, n_max, selection)
+    # featurize epilogue = weighted sum of exactly those states
+    normalize = bool(rng.integers(2))
+    w = rng.random(len(ref))
+    w = w + 0.05
+    if len(ref) > 1:
+        w[int(rng.integers(len(ref)))] = 0.0  # an unselected layer
+    w = (w / w.sum()).tolist()
+    feat = enc.forward_featurized(dev, w, normalize=normalize, n_max=n_max, selection=selection).cpu().numpy()
+    want = np.zeros(got[0].shape, dtype=np.float64)
+    for wi, h in zip(w, got.astype(np.float64)):
+        want += wi * (O.layer_norm(h, None, None) if normalize else h)
+    assert O.rel_err(feat, want) < 3e-6, (cfg, selection, normalize)
+    enc.close()
+    # 16-bit states are the rounded fp32 states of the same 16-bit encoder
+    dtype = ["bf16", "fp16"][int(rng.integers(2))]
+    enc16 = HipEncoder(cfg, weights, dtype=dtype)
+    a = enc16.forward(dev, n_max=n_max, selection=selection)
+    b = enc16.forward(dev, n_max=n_max, selection=selection, out_dtype=dtype)
+    assert torch.equal(a.to(b.dtype), b), (cfg, selection, dtype)
+    f16 = enc16.forward_featurized(dev, w, normalize=normalize, n_max=n_max, selection=selection).cpu().numpy()
+    want16 = np.zeros(got[0].shape, dtype=np.float64)
+    for wi, h in zip(w, a.cpu().numpy().astype(np.float64)):
+        want16 += wi * (O.layer_norm(h, None, None) if normalize else h)
+    assert O.rel_err(f16, want16) < 3e-6, (cfg, selection, normalize, dtype)
+    enc16.close()
