@@ -156,3 +156,39 @@ def test_random_forward_options_are_consistent(seed):
         want16 += wi * (O.layer_norm(h, None, None) if normalize else h)
     assert O.rel_err(f16, want16) < 3e-6, (cfg, selection, normalize, dtype)
     enc16.close()
+
+
+@pytest.mark.parametrize("name,lengths", [
+    ("tiny_wavlm", [640000]),                      # 40 s: T = 1999, far beyond the relative-position table's +-max_distance
+    ("tiny_wavlm_large", [400000, 30000, 401]),    # one long, one short, one single-frame utterance in the same batch
+    ("tiny_hubert", None),                         # 48 utterances, 400 .. 8000 samples
+    ("tiny_multires3", None),
+    ("tiny_distiller", None),
+    ("tiny_data2vec", [200000, 123457]),
+])
+def test_shape_extremes_match_the_oracle(name, lengths):
+    import torch
+
+    from s3prl_amd.encoder import HipEncoder
+    from s3prl_amd.synth import named_config, synth_wavs, synth_weights
+
+    cfg = named_config(name)
+    weights = synth_weights(cfg, 31)
+    if lengths is None:
+        rng = np.random.default_rng(32)
+        lengths = [int(x) for x in rng.integers(400, 8000, size=48)]
+    wavs = synth_wavs(lengths, 33)
+    ref = O.forward(cfg, weights, wavs, dtype=np.float32)
+    dev = [torch.from_numpy(w).cuda() for w in wavs]
+    valid = [cfg.valid_frames(n, max(lengths)) for n in lengths]
+    for dtype, tol in (("fp32", 1e-4), ("fp32x3", 2e-4), ("bf16", 6e-2)):
+        enc = HipEncoder(cfg, weights, dtype=dtype)
+        hs = enc.forward(dev).cpu().numpy()
+        assert hs.shape == (len(ref),) + ref[0].shape and np.isfinite(hs).all()
+        err = max(O.rel_err(hs[l], ref[l]) for l in range(len(ref)))
+        assert err < tol, (name, dtype, err)
+        if cfg.family != "multires_hubert":  # per utterance, over its valid frames only (SURVEY §8d, cfg5 rule)
+            for b, v in enumerate(valid):
+                e_b = max(O.rel_err(hs[l][b, :v], ref[l][b, :v]) for l in range(len(ref)))
+                assert e_b < tol * 3, (name, dtype, b, v, e_b)
+        enc.close()
