@@ -98,3 +98,43 @@ def test_graph_replay_stays_out_of_the_way_of_profiling_events_and_featurize(gol
     torch.cuda.synchronize()
     assert enc.graph_stats()["captures"] == 0 and torch.equal(out, ref)
     enc.close()
+
+
+@pytest.mark.parametrize("name", ["tiny_wavlm_large", "tiny_multires3"])
+def test_random_call_sequence_with_graph_replay_equals_eager(name):
+    """A serving-like stream of calls — a few recurring batch shapes, recurring output blocks, fresh waveforms every call,
+    occasionally a new larger shape that re-allocates the workspace — with graph replay on: every result equals the eager
+    encoder's, and most calls are replays."""
+    import torch
+
+    from s3prl_amd.encoder import HipEncoder
+    from s3prl_amd.synth import named_config, synth_wavs, synth_weights
+
+    cfg = named_config(name)
+    weights = synth_weights(cfg, 41)
+    eager, enc = HipEncoder(cfg, weights), HipEncoder(cfg, weights)
+    enc.graph_replay(True)
+    rng = np.random.default_rng(42)
+    shapes = [[3000, 2500], [4000], [3500, 3500, 1200]]
+    outs = {}
+    side = torch.cuda.Stream()
+    for it in range(60):
+        if it == 35:
+            shapes.append([9000, 7000, 8000, 6000])  # bigger than anything before: the workspace grows
+        base = shapes[int(rng.integers(len(shapes)))]
+        lengths = [base[0]] + [int(n - rng.integers(0, 300)) for n in base[1:]]  # same B and n_max, other ragged lengths
+        wavs = synth_wavs(lengths, 100 + it)
+        use_side = bool(rng.integers(2))
+        with (torch.cuda.stream(side) if use_side else contextlib.nullcontext()):
+            dev = _dev(wavs)
+            ref = eager.forward(dev)
+            key = (len(base), base[0], int(rng.integers(2)))
+            if key not in outs:
+                outs[key] = torch.empty_like(ref)
+            enc.forward(dev, out=outs[key])
+            torch.cuda.current_stream().synchronize()
+            assert torch.equal(outs[key], ref), (it, lengths, key)
+    st = enc.graph_stats()
+    assert st["replays"] >= 25 and st["captures"] >= len(outs) - 2, st
+    enc.close()
+    eager.close()
