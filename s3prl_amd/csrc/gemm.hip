@@ -287,10 +287,16 @@ __global__ __launch_bounds__(256, ROWB == 128 ? 2 : (GLDS ? 5 : 3)) void gemm_ke
     }
 }
 
+}  // namespace
+int g_gemm_lds_pad = 0;
+namespace {
+
 template <typename T, int ROWB, bool GLDS, bool VEC>
 hipError_t gemm_go(const GemmParams& p, dim3 grid, hipStream_t stream) {
-    constexpr int lds = 2 * (BM + BN) * ROWB;
-    static_assert(lds >= 4 * 8192, "epilogue staging must fit");
+    constexpr int lds0 = 2 * (BM + BN) * ROWB;
+    static_assert(lds0 >= 4 * 8192, "epilogue staging must fit");
+    // g_gemm_lds_pad (tuning key "gemm_lds_pad", occupancy probe): unused extra LDS so that fewer workgroups fit a CU
+    const int lds = lds0 + g_gemm_lds_pad;
     hipError_t e = ensure_dynamic_lds<gemm_kernel<T, ROWB, GLDS, VEC>>(lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((gemm_kernel<T, ROWB, GLDS, VEC>), grid, dim3(256), lds, stream, p);

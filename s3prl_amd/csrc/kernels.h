@@ -38,6 +38,7 @@ struct GemmParams {
     int variant = -1;  // tuning knob: -1 = library default (g_gemm_variant)
 };
 extern int g_gemm_variant;
+extern int g_gemm_lds_pad;  // occupancy probe: extra (unused) dynamic LDS per workgroup of gemm_kernel
 // gemm_x3.hip: fp32-class GEMM from three bf16 MFMAs per product (opt-in compute mode S3ENC_F32X3)
 bool gemm_x3_eligible(const GemmParams& p);
 hipError_t launch_gemm_x3(const GemmParams& p, hipStream_t stream);
