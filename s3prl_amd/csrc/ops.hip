@@ -11,6 +11,11 @@ int s3enc_set_tuning(const char* key, int32_t value) {
         g_gemm_variant = value;
         return 0;
     }
+    if (!strcmp(key, "gemm32_big")) {
+        if (value < 0 || value > 2) return fail("gemm32_big must be 0..2");
+        g_gemm32_big = value;
+        return 0;
+    }
     if (!strcmp(key, "gemm_lds_pad")) {
         if (value < 0 || value > 120 * 1024) return fail("gemm_lds_pad must be 0..122880");
         g_gemm_lds_pad = value;
