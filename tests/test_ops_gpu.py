@@ -434,3 +434,42 @@ def test_wavlm_gate_kernel():
         torch.cuda.synchronize()
         err = O.rel_err(out.cpu().numpy(), ref)
         assert err < 5e-6, f"wavlm gate {B}x{T}x{H}: rel-err {err:.3e}"
+
+
+@pytest.mark.parametrize("shape", [
+    # (batches, M, N, K, lda, rows of a conv-style A batch or None, act, residual, row_limit)
+    (1, 15968, 3072, 768, 768, None, 1, False, False),
+    (1, 1000, 768, 3072, 3072, None, 0, True, False),
+    (3, 3199, 512, 1536, 1024, 6399, 1, False, False),  # implicit conv: overlapping A rows, batch stride
+    (2, 499, 768, 512, 512, None, 0, False, True),
+    (1, 257, 256, 64, 64, None, 0, True, True),          # one row into the second 256-row tile
+])
+def test_gemm32_big_tile_is_bit_identical_to_the_default_kernel(shape):
+    """The opt-in 256x256 exact-fp32 tile (tuning key gemm32_big, gemm32big.hip): same instruction and per-accumulator k order
+    as gemm_kernel<float>, so every epilogue feature must reproduce the default kernel bit for bit."""
+    torch = _torch()
+    from s3prl_amd import _lib
+
+    lib = _lib.load()
+    nb, M, N, K, lda, rows, act, use_res, use_lim = shape
+    g = torch.Generator(device="cuda").manual_seed(zlib.crc32(repr(shape).encode()))
+    if rows is None:
+        A, a_bs = torch.randn(nb * M * lda, device="cuda", generator=g), M * lda
+    else:
+        A, a_bs = torch.randn(nb * rows * 512, device="cuda", generator=g), rows * 512
+    W = torch.randn(N, K, device="cuda", generator=g) / K ** 0.5
+    bias = torch.randn(N, device="cuda", generator=g)
+    res = torch.randn(nb * M * N, device="cuda", generator=g) if use_res else None
+    lim = torch.tensor([M - 7 * (b + 1) for b in range(nb)], dtype=torch.int32, device="cuda") if use_lim else None
+    outs = []
+    try:
+        for mode in (0, 2):
+            _lib.check(lib.s3enc_set_tuning(b"gemm32_big", mode))
+            out = torch.full((nb * M * N,), float("nan"), device="cuda")
+            _lib.check(lib.s3enc_op_gemm(0, _ptr(A), lda, a_bs, _ptr(W), _ptr(bias), M, N, K, nb, act, _ptr(res) if use_res else None,
+                                         _ptr(lim) if use_lim else None, _ptr(out), None, N, M * N, None))
+            torch.cuda.synchronize()
+            outs.append(out)
+    finally:
+        _lib.check(lib.s3enc_set_tuning(b"gemm32_big", 0))
+    assert torch.isfinite(outs[1]).all() and torch.equal(outs[0], outs[1])
