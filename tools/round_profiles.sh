@@ -28,6 +28,12 @@ for d in fp32 fp32x3 bf16; do
   python bench.py --model multires_hubert_base --dtype $d --no-cpu-baseline --steps 40 --warmup 3 > $out/bench_multires_hubert_base_$d.json 2>/dev/null
 done
 python tools/graph_latency.py > $out/graph_replay.md 2>/dev/null
+python tools/gemm_yardstick.py > $out/gemm_yardstick.md 2>/dev/null          # vendor BLAS beside the library's GEMMs (yardstick only)
+python tools/gemm32_big_check.py > $out/gemm32_big.md 2>/dev/null            # the opt-in 256x256 fp32 tile: identity + timing
+for m in mfma_peak gemm_loop_probe; do                                        # matrix-pipe ceilings and the fp32 loop's ingredients
+  [ -x tools/micro/$m ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 tools/micro/$m.hip -o tools/micro/$m 2>/dev/null
+  tools/micro/$m > $out/$m.md 2>/dev/null
+done
 python tools/parity_table.py > $out/parity.md 2> $out/parity.err
 # rocprofv3 kernel trace of the headline command (its own run: never combined with PMC passes)
 rocprofv3 --kernel-trace --stats -d $out/prof_fp32 -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-parity > $out/prof_fp32.log 2>&1
