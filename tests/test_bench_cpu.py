@@ -34,3 +34,15 @@ def test_strong_scaling_splits_the_global_batch():
 def test_single_rank_needs_no_launcher():
     line = _run(["--gpus", "1"])
     assert line["n_gpus"] == 1 and line["exchange_ok"]
+
+
+def test_tools_and_scripts_are_syntactically_valid():
+    """The measurement tools only run on the GPU box; keep them at least importable / parseable here."""
+    import glob
+    import py_compile
+    import subprocess
+
+    for path in sorted(glob.glob(os.path.join(ROOT, "tools", "*.py"))) + [os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py")]:
+        py_compile.compile(path, doraise=True)
+    for path in sorted(glob.glob(os.path.join(ROOT, "tools", "*.sh"))):
+        subprocess.run(["bash", "-n", path], check=True)
