@@ -123,24 +123,57 @@ def convert_fairseq_checkpoint(path: str, family: str, refresh: bool = False) ->
 
     import torch
 
-    out = os.path.join(os.path.dirname(os.path.abspath(path)), os.path.splitext(os.path.basename(path))[0] + ".converted.pt")
-    if os.path.isfile(out) and not refresh:
-        return out
-    try:
-        state = torch.load(path, map_location="cpu", weights_only=False)
-    except ModuleNotFoundError as e:  # pragma: no cover - depends on the pickled classes
-        raise RuntimeError(f"{path}: unpickling this fairseq checkpoint needs the module {e.name!r}; convert it with "
-                           f"s3prl's upstream/{family}/convert.py where fairseq is installed") from e
-    if "cfg" not in state or "model" not in state:
-        raise ValueError(f"{path} is not a fairseq checkpoint (needs 'cfg' and 'model')")
-    cfg = state["cfg"]
-    if not isinstance(cfg, dict):
-        from omegaconf import OmegaConf  # only reachable when omegaconf unpickled the object above
+    src = os.path.abspath(path)
+    name = os.path.splitext(os.path.basename(src))[0] + ".converted.pt"
+    out_dir = os.path.dirname(src)
+    if not os.access(out_dir, os.W_OK):  # read-only checkpoint store: convert into a per-user cache instead
+        import hashlib
 
-        cfg = OmegaConf.to_container(cfg)
-    conv = {"task_cfg": _plain(cfg["task"]), "model_cfg": _plain(cfg["model"]), "model_weight": state["model"]}
-    if family == "hubert":
-        dicts = (state.get("task_state") or {}).get("dictionaries") or []
-        conv["dictionaries_symbols"] = [list(getattr(d, "symbols", d)) for d in dicts]
-    torch.save(conv, out)
+        out_dir = os.path.join(os.environ.get("S3PRL_AMD_CACHE", os.path.join(os.path.expanduser("~"), ".cache", "s3prl_amd")),
+                               hashlib.sha1(src.encode()).hexdigest()[:12])
+        os.makedirs(out_dir, exist_ok=True)
+    out = os.path.join(out_dir, name)
+
+    def fresh():  # converted file present and not older than its source (refresh re-converts once, not once per rank)
+        return os.path.isfile(out) and os.path.getmtime(out) >= os.path.getmtime(src)
+
+    if fresh() and not refresh:
+        return out
+    # one converter at a time (every rank of a data-parallel job calls this at once): exclusive lock on a side file, then
+    # re-check — the ranks that waited find the finished file (the reference serialises the same step with FileLock,
+    # hubert/hubconf.py:46-56) — and the result appears atomically (temp file + os.replace), never half-written
+    import fcntl
+    import time
+
+    t_call = time.time()
+    with open(out + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if fresh() and (not refresh or os.path.getmtime(out) >= t_call - 1.0):
+                return out
+            try:
+                state = torch.load(src, map_location="cpu", weights_only=False)
+            except ModuleNotFoundError as e:  # pragma: no cover - depends on the pickled classes
+                raise RuntimeError(f"{path}: unpickling this fairseq checkpoint needs the module {e.name!r}; convert it "
+                                   f"with s3prl's upstream/{family}/convert.py where fairseq is installed") from e
+            if "cfg" not in state or "model" not in state:
+                raise ValueError(f"{path} is not a fairseq checkpoint (needs 'cfg' and 'model')")
+            cfg = state["cfg"]
+            if not isinstance(cfg, dict):
+                from omegaconf import OmegaConf  # only reachable when omegaconf unpickled the object above
+
+                cfg = OmegaConf.to_container(cfg)
+            conv = {"task_cfg": _plain(cfg["task"]), "model_cfg": _plain(cfg["model"]), "model_weight": state["model"]}
+            if family == "hubert":
+                dicts = (state.get("task_state") or {}).get("dictionaries") or []
+                conv["dictionaries_symbols"] = [list(getattr(d, "symbols", d)) for d in dicts]
+            tmp = f"{out}.tmp.{os.getpid()}"
+            try:
+                torch.save(conv, tmp)
+                os.replace(tmp, out)
+            finally:
+                if os.path.exists(tmp):
+                    os.remove(tmp)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return out

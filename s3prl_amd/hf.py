@@ -62,7 +62,10 @@ def load_hf_checkpoint(path: str) -> Tuple[EncoderConfig, Dict[str, np.ndarray],
         conv_pos=int(hc.get("num_conv_pos_embeddings", 128)), conv_pos_groups=int(hc.get("num_conv_pos_embedding_groups", 16)),
         feature_layer_norm=bool(hc.get("feat_proj_layer_norm", True)) if mt == "hubert" else True,
     )
-    pre = {"do_normalize": cfg.extractor_mode == "layer_norm", "norm_eps": 1e-7}
+    # without a preprocessor_config.json the reference's hf_hubert expert falls back to the facebook/hubert-base-ls960
+    # feature extractor (do_normalize=False, hf_hubert/expert.py:20-27), whatever the model's extractor mode; wav2vec2
+    # checkpoints ship the file (hf_wav2vec2 has no fallback), so the extractor mode decides there
+    pre = {"do_normalize": cfg.extractor_mode == "layer_norm" and mt != "hubert", "norm_eps": 1e-7}
     pp = os.path.join(path, "preprocessor_config.json")
     if os.path.isfile(pp):
         pre["do_normalize"] = bool(json.load(open(pp)).get("do_normalize", True))

@@ -10,9 +10,10 @@ from .expert import UpstreamExpert as _UpstreamExpert
 
 
 def wav2vec2_custom(ckpt: str, legacy: bool = False, fairseq: bool = False, refresh: bool = False, **kwargs):
+    # AssertionError like the reference entry (hubert/hubconf.py:36-41): the two loaders are mutually exclusive
     assert not (legacy and fairseq), (
-        "The option 'legacy' will directly load a fairseq checkpoint, while the option 'fairseq' will first convert the "
-        "fairseq checkpoint to be fairseq indenpendent and then load the checkpoint. These two options cannot be used jointly.")
+        f"{__name__}: pass either legacy=True (load through the fairseq package) or fairseq=True (convert the fairseq "
+        "checkpoint first), not both")
     if legacy:
         raise NotImplementedError(
             "wav2vec2: legacy=True loads the checkpoint through the `fairseq` package (LegacyUpstreamExpert), which the "

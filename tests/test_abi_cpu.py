@@ -29,7 +29,17 @@ def test_library_exports_every_declared_symbol():
     for sym in declared:
         assert hasattr(lib, sym), f"{sym} declared in s3enc.h but not exported by libs3enc.so"
     assert declared == set(_lib._PROTOS), "ctypes prototypes and header disagree"
-    assert lib.s3enc_version() == _lib.ABI_VERSION == 3
+    version = int(re.search(r"#define\s+S3ENC_VERSION\s+(\d+)", header).group(1))
+    assert lib.s3enc_version() == _lib.ABI_VERSION == version
+
+
+def test_graft_entry_build_passes_on_a_built_tree():
+    """The driver's build check: make is a no-op on a built tree and the version cross-check (library, ctypes mirror,
+    header) must agree — round 2 shipped a literal that went stale when the ABI version was raised."""
+    _built()
+    import __graft_entry__ as g
+
+    g.build()
 
 
 def test_struct_layout_matches_header(tmp_path):
