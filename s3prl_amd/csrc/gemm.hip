@@ -326,9 +326,12 @@ hipError_t launch_gemm(int dtype, const GemmParams& p0, hipStream_t stream) {
     GemmParams p = p0;
     if (p.variant < 0) p.variant = g_gemm_variant;
     if (p.M <= 0 || p.N <= 0 || p.batches <= 0) return hipSuccess;
-    if (dtype == F32 && gemm_x3_eligible(p)) return launch_gemm_x3(p, stream);
+    if (dtype == F32 && gemm_x3_eligible(p)) {
+        if (gemm_tile_eligible(3, p)) return launch_gemm_tile(3, p, stream);
+        return launch_gemm_x3(p, stream);
+    }
+    if (gemm_tile_eligible(dtype, p)) return launch_gemm_tile(dtype, p, stream);  // gemmt.hip: the default of the path's shapes
     if (gemm16_big_eligible(dtype, p)) return launch_gemm16_big(dtype, p, stream);
-    if (gemm32_big_eligible(dtype, p)) return launch_gemm32_big(p, stream);  // opt-in 256x256 fp32 tile (gemm32big.hip)
     p.variant &= 7 | 32;  // bit 5 (tuning): force the scalar epilogue
     {   // vector epilogue when every output / residual / bias access can be a 16-byte (8-byte for 16-bit) vector
         const uintptr_t al = (uintptr_t)p.out32 | (uintptr_t)p.residual | (uintptr_t)p.bias;

@@ -52,10 +52,12 @@ extern int g_gemm16_probe;
 extern int g_gemm_x3_mode;  // 0: gemm_x3.hip (two-stage lockstep), 1: the phased schedule of gemm16p.hip
 hipError_t launch_gemm_x3_phased(const GemmParams& p, hipStream_t stream);
 hipError_t launch_gemm16_phased(int dtype, int mode, const GemmParams& p, hipStream_t stream);
-// gemm32big.hip: exact fp32 on a 256x256 tile (half the staging bytes per MFMA); opt-in, bit-identical to gemm.hip's kernel
-extern int g_gemm32_big;  // 0 off, 1 where the tile count fills the CUs, 2 every eligible shape
-bool gemm32_big_eligible(int dtype, const GemmParams& p);
-hipError_t launch_gemm32_big(const GemmParams& p, hipStream_t stream);
+// gemmt.hip: (256 | 192 | 128 | 64) x 128 tiles, several independent workgroups per CU; fp32 results bit-identical to
+// gemm.hip's kernel.  Tuning keys: 0 off, 1 = tile height by shape, 2..5 = force 256 / 192 / 128 / 64 rows
+extern int g_gemm32_big;   // fp32 mode (default 1)
+extern int g_gemm_x3_tile; // S3ENC_F32X3 (dtype code 3 below: fp32 operands, the pair-packed p.W_x3)
+bool gemm_tile_eligible(int dtype, const GemmParams& p);
+hipError_t launch_gemm_tile(int dtype, const GemmParams& p, hipStream_t stream);
 hipError_t launch_gemm(int dtype, const GemmParams& p, hipStream_t stream);
 
 // ---- frontend.hip ---------------------------------------------------------------------------------------

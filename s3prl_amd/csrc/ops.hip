@@ -12,8 +12,13 @@ int s3enc_set_tuning(const char* key, int32_t value) {
         return 0;
     }
     if (!strcmp(key, "gemm32_big")) {
-        if (value < 0 || value > 2) return fail("gemm32_big must be 0..2");
+        if (value < 0 || value > 5) return fail("gemm32_big must be 0..5");
         g_gemm32_big = value;
+        return 0;
+    }
+    if (!strcmp(key, "gemm_x3_tile")) {
+        if (value < 0 || value > 5) return fail("gemm_x3_tile must be 0..5");
+        g_gemm_x3_tile = value;
         return 0;
     }
     if (!strcmp(key, "gemm_lds_pad")) {

@@ -443,10 +443,13 @@ def test_wavlm_gate_kernel():
     (3, 3199, 512, 1536, 1024, 6399, 1, False, False),  # implicit conv: overlapping A rows, batch stride
     (2, 499, 768, 512, 512, None, 0, False, True),
     (1, 257, 256, 64, 64, None, 0, True, True),          # one row into the second 256-row tile
+    (1, 193, 132, 16, 16, None, 1, True, True),          # a single K step, ragged N (clamped W rows), one row past 192
+    (2, 99, 2304, 768, 768, None, 0, False, False),      # a short utterance: the 64-row tile's home shape
 ])
 def test_gemm32_big_tile_is_bit_identical_to_the_default_kernel(shape):
-    """The opt-in 256x256 exact-fp32 tile (tuning key gemm32_big, gemm32big.hip): same instruction and per-accumulator k order
-    as gemm_kernel<float>, so every epilogue feature must reproduce the default kernel bit for bit."""
+    """The fp32 path's default GEMM (gemm32big.hip: 256 / 192 / 128 / 64 x 128 tiles, tuning key gemm32_big = 2..5, 1 = chosen
+    per shape): same instruction and per-accumulator k order as gemm_kernel<float> (gemm32_big = 0), so every tile height and
+    every epilogue feature must reproduce that kernel bit for bit — a row's rounding never depends on the tile choice."""
     torch = _torch()
     from s3prl_amd import _lib
 
@@ -463,7 +466,7 @@ def test_gemm32_big_tile_is_bit_identical_to_the_default_kernel(shape):
     lim = torch.tensor([M - 7 * (b + 1) for b in range(nb)], dtype=torch.int32, device="cuda") if use_lim else None
     outs = []
     try:
-        for mode in (0, 2):
+        for mode in (0, 1, 2, 3, 4, 5):
             _lib.check(lib.s3enc_set_tuning(b"gemm32_big", mode))
             out = torch.full((nb * M * N,), float("nan"), device="cuda")
             _lib.check(lib.s3enc_op_gemm(0, _ptr(A), lda, a_bs, _ptr(W), _ptr(bias), M, N, K, nb, act, _ptr(res) if use_res else None,
@@ -471,5 +474,7 @@ def test_gemm32_big_tile_is_bit_identical_to_the_default_kernel(shape):
             torch.cuda.synchronize()
             outs.append(out)
     finally:
-        _lib.check(lib.s3enc_set_tuning(b"gemm32_big", 0))
-    assert torch.isfinite(outs[1]).all() and torch.equal(outs[0], outs[1])
+        _lib.check(lib.s3enc_set_tuning(b"gemm32_big", 1))
+    assert torch.isfinite(outs[0]).all()
+    for mode, out in enumerate(outs[1:], start=1):
+        assert torch.equal(outs[0], out), f"gemm32_big = {mode} differs from the 128x128 kernel"

@@ -29,7 +29,6 @@ for d in fp32 fp32x3 bf16; do
 done
 python tools/graph_latency.py > $out/graph_replay.md 2>/dev/null
 python tools/gemm_yardstick.py > $out/gemm_yardstick.md 2>/dev/null          # vendor BLAS beside the library's GEMMs (yardstick only)
-python tools/gemm32_big_check.py > $out/gemm32_big.md 2>/dev/null            # the opt-in 256x256 fp32 tile: identity + timing
 for m in mfma_peak gemm_loop_probe; do                                        # matrix-pipe ceilings and the fp32 loop's ingredients
   [ -x tools/micro/$m ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 tools/micro/$m.hip -o tools/micro/$m 2>/dev/null
   tools/micro/$m > $out/$m.md 2>/dev/null
