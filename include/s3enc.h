@@ -237,8 +237,9 @@ int s3enc_op_wavlm_gate(const float* x, const float* grep_w, const float* grep_b
 int s3enc_op_layernorm(int32_t dtype, const float* x, const float* gamma, const float* beta, int32_t rows,
                        int32_t C, int32_t act, float* out32, void* out16, void* stream);
 
-/* Multi-head self-attention on a fused (B*T, 3D) q|k|v buffer (q pre-scaled), head_dim 64, keys >= valid[b]
- * masked; optional WavLM gated relative-position bias: score += gate[b][h][i] * table[h][clamp(j-i, -R, R) + R]
+/* Multi-head self-attention on a fused (B*T, 3D) q|k|v buffer, head_dim 64, keys >= valid[b] masked.  q arrives
+ * pre-scaled by head_dim^-0.5 — for dtype S3ENC_BF16 / S3ENC_F16 by head_dim^-0.5 * log2(e): the 16-bit kernels
+ * work on base-2 scores, the engine folds either factor into W_q at s3enc_create; optional WavLM gated relative-position bias: score += gate[b][h][i] * table[h][clamp(j-i, -R, R) + R]
  * with a (H, 2R+1) table (the bucket of wavlm/modules.py:418-446 is constant for |j-i| >= max_distance, so
  * R = max_distance serves every T). */
 int s3enc_op_attention(int32_t dtype, const void* qkv, void* out, const int32_t* valid, int32_t B, int32_t T,

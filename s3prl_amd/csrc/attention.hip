@@ -13,7 +13,18 @@
 // fp32 path: v_mfma_f32_32x32x2_f32 (exact);  16-bit path: v_mfma_f32_32x32x16_{bf16,f16} with V staged
 // transposed in LDS.  Padded queries are computed like the reference does; keys beyond
 // valid[b] are skipped tile-wise and masked inside the last tile.
+#include <type_traits>
+
 #include "kernels.h"
+
+// Timing probes (results are garbage by design): compiled in only by tools/micro/attn_lab.hip
+//   1 = stage only the first K/V tile (no global loads / LDS stores afterwards), 2 = no softmax VALU (p = score),
+//   4 = no P.V MFMAs, 8 = no Q.K MFMAs, 16 = no per-tile barrier
+#ifdef S3_ATTN_PROBE
+#define S3_PROBE(p_, bit_) ((p_).probe & (bit_))
+#else
+#define S3_PROBE(p_, bit_) 0
+#endif
 
 namespace s3 {
 namespace {
@@ -23,6 +34,27 @@ constexpr int QT = 128;       // queries per workgroup (4 waves x 32)
 constexpr int KT = 32;        // keys per tile
 constexpr int KS32 = HD + 4;  // fp32 LDS row stride (floats): 272 B rows -> conflict-free ds_read_b128
 constexpr int BIAS_PAD = 64;  // WavLM bias window: entries past T + QT - 1 so that the keys of a partial last tile stay in range
+
+// XCD-aware work map.  Workgroup w of a 1-D grid runs on XCD w % 8 (each XCD has a private 4 MiB L2).  The query blocks of
+// one (batch, head) unit all read that unit's K and V: with the plain (q-block, head, batch) grid they land on `nqb`
+// DIFFERENT XCDs and every L2 fetches its own copy (round 2: 210 MB fetched per launch for 74 MB of q|k|v, L2 hit 0.42 — the
+// 16-bit kernel ran at the HBM rate, not at any on-chip limit).  Here XCD x owns the units u = x (mod 8) and runs a unit's
+// query blocks back to back, so K / V come from HBM once.  The launcher pads the grid to 8 * ceil(units / 8) * nqb.
+struct AttnWork {
+    int b, head, qb;
+    bool live;
+};
+__device__ __forceinline__ AttnWork attn_work(const AttnParams& p) {
+    const int nqb = (p.T + 127) / 128;
+    const int wg = blockIdx.x, xcd = wg & 7, local = wg >> 3;
+    const int unit = xcd + 8 * (local / nqb);
+    AttnWork w;
+    w.qb = local % nqb;
+    w.live = unit < p.B * p.H;
+    w.b = unit / p.H;
+    w.head = unit % p.H;
+    return w;
+}
 
 __device__ __forceinline__ int crow(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
@@ -47,18 +79,20 @@ struct BiasCtx {
     int qpos;  // query index + (T-1) offset folded:  idx = key - q + (T-1)
 };
 
-__global__ __launch_bounds__(256) void attn_f32_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, 3) void attn_f32_kernel(AttnParams p) {
     // K and V tiles double-buffered in LDS; the next tile's global loads are in flight (registers) while the current
     // tile is multiplied: one barrier per 32 keys
     __shared__ __attribute__((aligned(16))) float Ks[2 * KT * KS32];
     __shared__ __attribute__((aligned(16))) float Vs[2 * KT * KS32];
-    const int b = blockIdx.z, head = blockIdx.y;
+    const AttnWork wk = attn_work(p);
+    if (!wk.live) return;
+    const int b = wk.b, head = wk.head;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
     const int D = p.H * HD;
     const long ld = 3L * D;
     const float* base = (const float*)p.qkv + (long)b * p.T * ld + head * HD;
-    const int q_g = blockIdx.x * QT + wave * 32 + l31;
+    const int q_g = wk.qb * QT + wave * 32 + l31;
     const int q_c = q_g < p.T ? q_g : p.T - 1;
 
     // Q fragment: B operand, lane (q, half) holds Q[q][half*32 + s], s = 0..31
@@ -83,12 +117,12 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnParams p) {
     if (p.bias_table) {
         const int R = p.table_R;
         const float* src = p.bias_table + (long)head * (2 * R + 1) + R;
-        const int rel0 = -((int)blockIdx.x * QT + QT - 1);  // smallest key - query this workgroup can meet
+        const int rel0 = -(wk.qb * QT + QT - 1);  // smallest key - query this workgroup can meet
         for (int i = threadIdx.x; i < p.T + QT - 1 + BIAS_PAD; i += 256) bias_s[i] = src[min(max(rel0 + i, -R), R)];
         btab = bias_s;  // made visible by the first __syncthreads() of the key loop
     }
     const float gate = (btab && p.gate) ? p.gate[((long)b * p.H + head) * p.T + q_c] : 1.f;
-    const int bias_off = (int)blockIdx.x * QT + QT - 1;  // window index = (key - query) + bias_off
+    const int bias_off = wk.qb * QT + QT - 1;  // window index = (key - query) + bias_off
 
     f32x16 o0, o1;
 #pragma unroll
@@ -215,20 +249,23 @@ template <> struct Mma16<f16_tag> {
     }
 };
 
-// BIAS: the WavLM relative-position bias path compiled in (134 registers: 3 waves per SIMD; capped at 128 its 16 table
-// reads in flight spill to scratch).  The bias-free variant fits 115 registers = 4 waves per SIMD; 3 vs 4 waves is a
-// wash on HuBERT shapes (A/B with the `attn_lds_pad` tuning knob: 0.61 vs 0.61 ms per HuBERT-base forward).
+// BIAS: the WavLM relative-position bias path compiled in (its 16 table reads in flight need > 168 registers: two waves per
+// SIMD); the bias-free variant fits 152 registers = 3 waves per SIMD.
+// Operand contract of the 16-bit kernels: q arrives pre-scaled by head_dim^-0.5 * log2(e) (folded into W_q / b_q at pack
+// time), so the scores are base-2 logarithms and the softmax is exp2 without a per-score multiply.
 template <typename T, bool BIAS>
-__global__ __launch_bounds__(256, 3) void attn_h16_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, BIAS ? 2 : 3) void attn_h16_kernel(AttnParams p) {
     __shared__ __attribute__((aligned(16))) u16 Ks[2 * KBUF16];
     __shared__ __attribute__((aligned(16))) u16 Vt[2 * VBUF16];
-    const int b = blockIdx.z, head = blockIdx.y;
+    const AttnWork wk = attn_work(p);
+    if (!wk.live) return;
+    const int b = wk.b, head = wk.head;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
     const int D = p.H * HD;
     const long ld = 3L * D;
     const u16* base = (const u16*)p.qkv + (long)b * p.T * ld + head * HD;
-    const int q_g = blockIdx.x * QT + wave * 32 + l31;
+    const int q_g = wk.qb * QT + wave * 32 + l31;
     const int q_c = q_g < p.T ? q_g : p.T - 1;
 
     // Q fragment (B operand): step st covers dims st*16 .. +15, this half-wave holds 8 of them
@@ -245,17 +282,32 @@ __global__ __launch_bounds__(256, 3) void attn_h16_kernel(AttnParams p) {
     if (BIAS && p.bias_table) {
         const int R = p.table_R;
         const float* src = p.bias_table + (long)head * (2 * R + 1) + R;
-        const int rel0 = -((int)blockIdx.x * QT + QT - 1);  // smallest key - query this workgroup can meet
+        const int rel0 = -(wk.qb * QT + QT - 1);  // smallest key - query this workgroup can meet
         for (int i = threadIdx.x; i < p.T + QT - 1 + BIAS_PAD; i += 256) bias_s[i] = src[min(max(rel0 + i, -R), R)];
         btab = bias_s;  // made visible by the first __syncthreads() of the key loop
     }
     const float gate = (btab && p.gate) ? p.gate[((long)b * p.H + head) * p.T + q_c] : 1.f;
-    const int bias_off = (int)blockIdx.x * QT + QT - 1;  // window index = (key - query) + bias_off
+    const int bias_off = wk.qb * QT + QT - 1;  // window index = (key - query) + bias_off
 
-    f32x16 o0, o1;
+    // Softmax bookkeeping (round 3: the kernel was VALU-issue-bound — ~300 VALU + 32 exp per 64 keys beside 16 MFMAs, a
+    // third of them address arithmetic for the staging loads):
+    //   * the scores arrive in the LOG2 domain (log2(e) is folded into W_q / b_q with head_dim^-0.5 at pack time) and
+    //     ALREADY relative to the running reference m: the accumulator of the S^T = K Q^T chain starts at -m (`negm`, 16
+    //     registers that only change when the reference moves), so p = exp2(score) with no per-score multiply-add;
+    //   * (the row sum stays on the VALU: carrying it on the matrix pipe — a third accumulator block with an all-ones A
+    //     fragment — costs 20 registers and, with them, the third wave per SIMD);
+    //   * the reference only moves when some query's scores exceed it by more than 2^8 (deferred max); the first 32 keys
+    //     set it exactly (a reference of 0 could underflow every p of a row);
+    //   * staging pointers advance by a constant per tile (the clamp to the last frame is only computed for the last tile)
+    //     and the last (partial) tile is peeled, so the steady-state body has no mask / half-count branches;
+    //   * one 32-key score tile is live at a time: with both halves' chains in flight (and their K / V fragments
+    //     pre-loaded) the kernel needs 216 registers = two waves per SIMD, and was slower than this form at three.
+    f32x16 o0, o1, negm;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) o0[r] = o1[r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
+    for (int r = 0; r < 16; ++r) o0[r] = o1[r] = negm[r] = 0.f;
+    float l_run = 0.f;
+    bool first = true;
+    const float gate2 = gate * 1.44269504088896340736f;  // the bias joins log2-domain scores
 
     const int valid = p.valid[b];
     const int ntiles = (valid + KT16 - 1) / KT16;
@@ -263,89 +315,109 @@ __global__ __launch_bounds__(256, 3) void attn_h16_kernel(AttnParams p) {
     const int krow = tid >> 3, kc8 = tid & 7;
     const int vj = tid & 31, vdg = tid >> 5;
     u32x4 kreg[2], vreg[2];
-    auto clampk = [&](int kr) { return kr < p.T ? kr : p.T - 1; };
-#define A16_LOAD(kt_)                                                                               \
-    {                                                                                               \
-        const int k0_ = (kt_) * KT16;                                                               \
-        kreg[0] = *(const u32x4*)(base + (long)clampk(k0_ + krow) * ld + D + kc8 * 8);              \
-        kreg[1] = *(const u32x4*)(base + (long)clampk(k0_ + krow + 32) * ld + D + kc8 * 8);         \
-        vreg[0] = *(const u32x4*)(base + (long)clampk(k0_ + 2 * vj) * ld + 2 * D + vdg * 8);        \
-        vreg[1] = *(const u32x4*)(base + (long)clampk(k0_ + 2 * vj + 1) * ld + 2 * D + vdg * 8);    \
-    }
-#define A16_STORE(buf_)                                                                             \
-    {                                                                                               \
-        u16* ks_ = Ks + (buf_) * KBUF16;                                                            \
-        u16* vt_ = Vt + (buf_) * VBUF16;                                                            \
-        *(u32x4*)(ks_ + krow * KS16 + kc8 * 8) = kreg[0];                                           \
-        *(u32x4*)(ks_ + (krow + 32) * KS16 + kc8 * 8) = kreg[1];                                    \
-        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                          \
-            const unsigned a_ = vreg[0][i_], b_ = vreg[1][i_];                                      \
-            *(unsigned*)(vt_ + (vdg * 8 + 2 * i_) * VS16 + 2 * vj) = (a_ & 0xffffu) | (b_ << 16);   \
-            *(unsigned*)(vt_ + (vdg * 8 + 2 * i_ + 1) * VS16 + 2 * vj) = (a_ >> 16) | (b_ & 0xffff0000u); \
-        }                                                                                           \
-    }
-    A16_LOAD(0)
-    A16_STORE(0)
+    const u16 *kp0, *kp1, *vp0, *vp1;
+    auto set_ptrs = [&](int kt) {  // rows past the last frame re-read it (their scores are masked)
+        auto clampk = [&](int kr) { return kr < p.T ? kr : p.T - 1; };
+        const int k0_ = kt * KT16;
+        kp0 = base + (long)clampk(k0_ + krow) * ld + D + kc8 * 8;
+        kp1 = base + (long)clampk(k0_ + krow + 32) * ld + D + kc8 * 8;
+        vp0 = base + (long)clampk(k0_ + 2 * vj) * ld + 2 * D + vdg * 8;
+        vp1 = base + (long)clampk(k0_ + 2 * vj + 1) * ld + 2 * D + vdg * 8;
+    };
+    auto load_tile = [&]() {
+        kreg[0] = *(const u32x4*)kp0;
+        kreg[1] = *(const u32x4*)kp1;
+        vreg[0] = *(const u32x4*)vp0;
+        vreg[1] = *(const u32x4*)vp1;
+    };
+    u16* const ks_st = Ks + krow * KS16 + kc8 * 8;
+    u16* const vt_st = Vt + (vdg * 8) * VS16 + 2 * vj;
+    auto store_tile = [&](int buf) {
+        u16* ks_ = ks_st + buf * KBUF16;
+        u16* vt_ = vt_st + buf * VBUF16;
+        *(u32x4*)ks_ = kreg[0];
+        *(u32x4*)(ks_ + 32 * KS16) = kreg[1];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned a_ = vreg[0][i], b_ = vreg[1][i];
+            *(unsigned*)(vt_ + (2 * i) * VS16) = (a_ & 0xffffu) | (b_ << 16);
+            *(unsigned*)(vt_ + (2 * i + 1) * VS16) = (a_ >> 16) | (b_ & 0xffff0000u);
+        }
+    };
+    set_ptrs(0);
+    load_tile();
+    store_tile(0);
     __syncthreads();
+    const long tstride = (long)KT16 * ld;  // elements between the same row of consecutive tiles
+    const u16* const kf_rd = Ks + l31 * KS16 + 8 * half;
+    const u16* const vf_rd = Vt + l31 * VS16 + 4 * half;
 
-    for (int kt = 0; kt < ntiles; ++kt) {
-        if (kt + 1 < ntiles) A16_LOAD(kt + 1)
-        const u16* ks = Ks + (kt & 1) * KBUF16;
-        const u16* vt = Vt + (kt & 1) * VBUF16;
-
-        // the 64 staged keys are consumed as two 32-key halves (scores -> softmax -> P.V per half): half the score
-        // registers of a 64-key pass, which keeps the kernel at <= 128 VGPRs (4 waves per SIMD); with the deferred
-        // max the second softmax pass costs nothing extra.
-        // VALU, not the matrix pipe, bounds this kernel at the 16-bit MFMA rate, so the softmax is kept lean:
-        // bias / mask passes only where they apply, and the running max is only raised (and O, l rescaled) when some
-        // query's tile max exceeds it by more than 8 — softmax is invariant to the reference point, e^8 fits every
-        // operand type, and after the first tile the rescale of the 32 O registers is almost never needed.
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int k0 = kt * KT16 + h * 32;
-            if (k0 >= valid) break;  // wave-uniform: the whole half is masked
-            f32x16 sc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+    // one 64-key tile.  FULL: every key is valid (all tiles but the last)
+    auto tile = [&](auto full_c, int kt) {
+        constexpr bool FULL = decltype(full_c)::value;
+        const u16* ks = kf_rd + (kt & 1) * KBUF16;
+        const u16* vt = vf_rd + (kt & 1) * VBUF16;
+        const bool two = FULL || kt * KT16 + 32 < valid;  // wave-uniform: the second half has at least one valid key
+        auto scores = [&](int h) {
+            f32x16 sc = negm;
+            if (S3_PROBE(p, 8)) return sc;
 #pragma unroll
             for (int st = 0; st < 4; ++st) {
-                const uint4 kf = *(const uint4*)(ks + (h * 32 + l31) * KS16 + st * 16 + 8 * half);
+                const uint4 kf = *(const uint4*)(ks + h * 32 * KS16 + st * 16);
                 sc = Mma16<T>::run(kf, qf[st], sc);
             }
+            return sc;
+        };
+        // softmax of one 32-key half (`sc`: its scores minus the reference) and O^T += V^T P^T, la += 1 P^T
+        auto half_step = [&](f32x16& sc, int h) {
+            const int k0_ = kt * KT16 + h * 32;
             if (BIAS && btab) {
-                {
-                    const float* bb = btab + (k0 + 4 * half - q_c + bias_off);  // branch-free, see attn_f32_kernel
+                const float* bb = btab + (k0_ + 4 * half - q_c + bias_off);  // branch-free, see attn_f32_kernel
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) sc[r] = fmaf(gate, bb[(r & 3) + 8 * (r >> 2)], sc[r]);
-                }
+                for (int r = 0; r < 16; ++r) sc[r] = fmaf(gate2, bb[(r & 3) + 8 * (r >> 2)], sc[r]);
             }
-            if (k0 + 32 > valid) {
+            if (!FULL && k0_ + 32 > valid) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) sc[r] = k0 + crow(r, half) < valid ? sc[r] : -INFINITY;
+                for (int r = 0; r < 16; ++r) sc[r] = k0_ + crow(r, half) < valid ? sc[r] : -INFINITY;
             }
-            float mx = sc[0];
+            if (S3_PROBE(p, 2)) goto pv;
+            {
+            // max of the 16 scores as v_med3_f32(a, b, +inf): fmaxf on MFMA outputs costs a canonicalising v_max per input
+            float mx = __builtin_amdgcn_fmed3f(sc[0], sc[1], INFINITY);
 #pragma unroll
-            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sc[r]);
+            for (int r = 2; r < 16; ++r) mx = __builtin_amdgcn_fmed3f(mx, sc[r], INFINITY);
             mx = xhalf_max(mx);
-            if (__any(mx > m_run + 8.f)) {
-                const float m_new = fmaxf(m_run, mx);
-                const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * 1.44269504088896340736f);
-                l_run *= alpha;
-                m_run = m_new;
+            if (__builtin_expect(first || __any(mx > 8.f), 0)) {
+                // move the reference: exactly onto the maximum for the first keys of a row, up by the excess afterwards
+                const float delta = first ? mx : fmaxf(mx, 0.f);
+                const float alpha = __builtin_amdgcn_exp2f(-delta);  // first: O = l = 0, the scale is irrelevant
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     o0[r] *= alpha;
                     o1[r] *= alpha;
+                    sc[r] -= delta;
+                    negm[r] -= delta;
                 }
+                l_run *= alpha;
+                first = false;
             }
-            const float mneg = -m_run * 1.44269504088896340736f;
-            float ps = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                sc[r] = __builtin_amdgcn_exp2f(fmaf(sc[r], 1.44269504088896340736f, mneg));
-                ps += sc[r];
+            for (int r = 0; r < 16; ++r) sc[r] = __builtin_amdgcn_exp2f(sc[r]);
+            {
+                float ps0 = sc[0] + sc[1], ps1 = sc[2] + sc[3];
+#pragma unroll
+                for (int r = 4; r < 16; r += 4) {
+                    ps0 += sc[r] + sc[r + 1];
+                    ps1 += sc[r + 2] + sc[r + 3];
+                }
+                l_run += ps0 + ps1;
             }
-            l_run += ps;
+            }
+        pv:
+            if (S3_PROBE(p, 4)) {
+                l_run += sc[0] + sc[5] + sc[11];
+                return;
+            }
             // P^T as B operand: step u uses regs 8u..8u+7  <->  keys 32h + 16u + {0,1,2,3,8,9,10,11} + 4*half
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -354,21 +426,41 @@ __global__ __launch_bounds__(256, 3) void attn_h16_kernel(AttnParams p) {
                 pf.y = Cvt<T>::pack2(sc[8 * u + 2], sc[8 * u + 3]);
                 pf.z = Cvt<T>::pack2(sc[8 * u + 4], sc[8 * u + 5]);
                 pf.w = Cvt<T>::pack2(sc[8 * u + 6], sc[8 * u + 7]);
-                const u16* v0 = vt + l31 * VS16 + 32 * h + 16 * u + 4 * half;
-                const u16* v1 = v0 + 32 * VS16;
+                const u16* v0 = vt + 32 * h + 16 * u;
                 const uint2 a00 = *(const uint2*)(v0), a01 = *(const uint2*)(v0 + 8);
-                const uint2 a10 = *(const uint2*)(v1), a11 = *(const uint2*)(v1 + 8);
+                const uint2 a10 = *(const uint2*)(v0 + 32 * VS16), a11 = *(const uint2*)(v0 + 32 * VS16 + 8);
                 o0 = Mma16<T>::run(make_uint4(a00.x, a00.y, a01.x, a01.y), pf, o0);
                 o1 = Mma16<T>::run(make_uint4(a10.x, a10.y, a11.x, a11.y), pf, o1);
             }
+        };
+        f32x16 sc = scores(0);
+        half_step(sc, 0);
+        if (two) {
+            sc = scores(1);
+            half_step(sc, 1);
         }
-        if (kt + 1 < ntiles) A16_STORE((kt + 1) & 1)
-        __syncthreads();
+    };
+
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const bool more = kt + 1 < ntiles;
+        if (more) {
+            if (kt + 2 == ntiles) {
+                set_ptrs(kt + 1);  // the last tile: rows may run past the last frame
+            } else {
+                kp0 += tstride;
+                kp1 += tstride;
+                vp0 += tstride;
+                vp1 += tstride;
+            }
+            if (!S3_PROBE(p, 1)) load_tile();
+            tile(std::true_type{}, kt);
+            if (!S3_PROBE(p, 1)) store_tile((kt + 1) & 1);
+        } else {
+            tile(std::false_type{}, kt);
+        }
+        if (!S3_PROBE(p, 16)) __syncthreads();
     }
-#undef A16_LOAD
-#undef A16_STORE
-    const float l_tot = xhalf_sum(l_run);
-    const float inv = 1.f / l_tot;
+    const float inv = 1.f / xhalf_sum(l_run);
     if (q_g < p.T) {
         u16* op = (u16*)p.out + ((long)b * p.T + q_g) * D + head * HD + 4 * half;
 #pragma unroll
@@ -393,13 +485,15 @@ __global__ __launch_bounds__(256, 3) void attn_x3_kernel(AttnParams p) {
     u16* Ks = (u16*)dyn_x3;                       // [plane][buffer][KBUF16]
     u16* Vt = Ks + 4 * KBUF16;                    // [plane][buffer][VBUF16]
     float* bias_s = (float*)(Vt + 4 * VBUF16);    // WavLM: the workgroup's (T+127)-entry table window
-    const int b = blockIdx.z, head = blockIdx.y;
+    const AttnWork wk = attn_work(p);
+    if (!wk.live) return;
+    const int b = wk.b, head = wk.head;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
     const int D = p.H * HD;
     const long ld = 3L * D;
     const float* base = (const float*)p.qkv + (long)b * p.T * ld + head * HD;
-    const int q_g = blockIdx.x * QT + wave * 32 + l31;
+    const int q_g = wk.qb * QT + wave * 32 + l31;
     const int q_c = q_g < p.T ? q_g : p.T - 1;
 
     // Q fragments (B operand), split once: step st covers dims st*16 .. +15, this half-wave holds 8 of them
@@ -413,12 +507,12 @@ __global__ __launch_bounds__(256, 3) void attn_x3_kernel(AttnParams p) {
     if (p.bias_table) {
         const int R = p.table_R;
         const float* src = p.bias_table + (long)head * (2 * R + 1) + R;
-        const int rel0 = -((int)blockIdx.x * QT + QT - 1);  // smallest key - query this workgroup can meet
+        const int rel0 = -(wk.qb * QT + QT - 1);  // smallest key - query this workgroup can meet
         for (int i = threadIdx.x; i < p.T + QT - 1 + BIAS_PAD; i += 256) bias_s[i] = src[min(max(rel0 + i, -R), R)];
         btab = bias_s;  // made visible by the first __syncthreads()
     }
     const float gate = (btab && p.gate) ? p.gate[((long)b * p.H + head) * p.T + q_c] : 1.f;
-    const int bias_off = (int)blockIdx.x * QT + QT - 1;  // window index = (key - query) + bias_off
+    const int bias_off = wk.qb * QT + QT - 1;  // window index = (key - query) + bias_off
 
     f32x16 o0, o1;
 #pragma unroll
@@ -604,7 +698,9 @@ int g_attn_lds_pad = 0;  // tuning: extra dynamic LDS per workgroup of the 16-bi
 
 hipError_t launch_attention(int dtype, const AttnParams& p, hipStream_t s) {
     if (p.B <= 0 || p.T <= 0) return hipSuccess;
-    dim3 grid((p.T + QT - 1) / QT, p.H, p.B), block(256);
+    static_assert(QT == 128, "attn_work assumes 128 queries per workgroup");
+    const int units8 = (p.B * p.H + 7) / 8;
+    dim3 grid((unsigned)(8 * units8 * ((p.T + QT - 1) / QT))), block(256);  // XCD-aware 1-D work map (attn_work)
     const size_t dyn = p.bias_table ? (size_t)(p.T + QT - 1 + BIAS_PAD) * sizeof(float) : 0;  // the workgroup's table window
     if (dyn > 24 * 1024) return hipErrorInvalidValue;  // T <= 6017 frames (120 s): the window must fit beside K/V (engine checks)
     switch (dtype) {

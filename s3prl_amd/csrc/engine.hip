@@ -301,7 +301,10 @@ int s3enc_create(const s3enc_config* cfg, const s3enc_tensor* tensors, int32_t n
     }
 
     // ---- transformer layers ----
-    const float qscale = 1.0f / std::sqrt((float)(D / H));
+    // q *= head_dim^-0.5 is folded into W_q, b_q; the 16-bit attention kernels additionally want log2-domain scores
+    // (attention.hip: softmax as exp2 with no per-score multiply), so those handles fold log2(e) in as well — one rounding
+    // of the weight to the operand type either way.  The exact-fp32 and split-precision handles keep the power-of-two scale.
+    const float qscale = (1.0f / std::sqrt((float)(D / H))) * (e->dtype != F32 ? 1.44269504088896340736f : 1.0f);
     // one TransformerSentenceEncoderLayer named `p` (…layers.N); returns non-zero after fail() (e is already deleted)
     auto load_layer = [&](const std::string& p, LayerW& L) -> int {
         std::vector<float> w(3L * D * D), bb(3L * D);

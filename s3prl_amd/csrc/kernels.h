@@ -128,6 +128,7 @@ struct AttnParams {
     const float* bias_table;  // WavLM: [H][2R+1], entry (h, clamp(key - query, -R, R) + R), or null
     int table_R = 0;
     const float* gate;        // WavLM: [B][H][T] or null (then gate = 1)
+    int probe = 0;            // timing probes (tools/micro/attn_lab.hip builds the kernels with S3_ATTN_PROBE; ignored otherwise)
 };
 extern int g_attn_lds_pad;
 hipError_t launch_attention(int dtype, const AttnParams& p, hipStream_t s);

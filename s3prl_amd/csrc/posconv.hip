@@ -16,6 +16,36 @@ namespace {
 
 constexpr int PC_TM = 64;  // output frames per workgroup
 
+// XCD-aware work map (1-D grid; workgroup w runs on XCD w % 8, each with a private 4 MiB L2).  Every workgroup of a group
+// streams that group's whole weight slice (Dg x Dg x K: 1.2 MB fp32 at HuBERT-base); with the plain (frame tile, group,
+// batch) grid the workgroups of ONE group are spread over all eight XCDs and every L2 keeps re-fetching all 16 slices
+// (round 2: 2.4 GB fetched per launch for 117 MB algorithmic, L2 hit 0.50).  Here XCD x owns the groups g = x (mod 8):
+// two slices (2.4 MB) stay L2-resident while the XCD sweeps their (batch, frame tile) workgroups.  Used when G % 8 == 0
+// (the released models: G = 16), else the plain order.
+struct PcWork {
+    int b, g, tile;
+    bool live;
+};
+__device__ __forceinline__ PcWork pc_work(const PosConvParams& p, int ntiles) {
+    PcWork w;
+    const int wg = blockIdx.x;
+    if (p.G & 7) {
+        w.tile = wg % ntiles;
+        const int r = wg / ntiles;
+        w.g = r % p.G;
+        w.b = r / p.G;
+        w.live = w.b < p.B;
+        return w;
+    }
+    const int per = ntiles * p.B, xcd = wg & 7, local = wg >> 3;
+    w.g = xcd + 8 * (local / per);
+    const int rem = local % per;
+    w.b = rem / ntiles;
+    w.tile = rem % ntiles;
+    w.live = w.g < p.G;
+    return w;
+}
+
 template <int DG>
 __global__ __launch_bounds__(256) void posconv_kernel(PosConvParams p) {
     constexpr int NT = DG / 16;       // 16-wide output-channel tiles
@@ -29,8 +59,10 @@ __global__ __launch_bounds__(256) void posconv_kernel(PosConvParams p) {
     float* xs = lds;
     float* wl = lds + ((rows * RS + 3) & ~3);
 
-    const int b = blockIdx.z, g = blockIdx.y;
-    const int t0 = blockIdx.x * PC_TM;
+    const PcWork wk = pc_work(p, (p.T + PC_TM - 1) / PC_TM);
+    if (!wk.live) return;
+    const int b = wk.b, g = wk.g;
+    const int t0 = wk.tile * PC_TM;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, kk = lane >> 4;
     const int pad = p.pad >= 0 ? p.pad : K / 2;
@@ -110,7 +142,7 @@ hipError_t pc_launch(const PosConvParams& p, hipStream_t s) {
     const size_t lds = (size_t)(((rows * (DG + 8) + 3) & ~3) + 2 * DG * DG) * sizeof(float);
     hipError_t e = ensure_dynamic_lds<posconv_kernel<DG>>((int)lds);
     if (e != hipSuccess) return e;
-    dim3 grid((p.T + PC_TM - 1) / PC_TM, p.G, p.B);
+    dim3 grid((unsigned)(((p.T + PC_TM - 1) / PC_TM) * p.G * p.B));  // 1-D: pc_work maps it XCD-aware (G % 8 == 0: same count)
     hipLaunchKernelGGL(posconv_kernel<DG>, grid, dim3(256), lds, s, p);
     return hipGetLastError();
 }
@@ -160,8 +192,10 @@ __global__ __launch_bounds__(256) void posconv16_kernel(PosConvParams p) {
     char* win = lds16;
     char* wl = lds16 + NS * WIN;  // [plane][buffer][WBUF]
 
-    const int b = blockIdx.z, g = blockIdx.y;
-    const int t0 = blockIdx.x * TMF;
+    const PcWork wk = pc_work(p, (p.T + TMF - 1) / TMF);
+    if (!wk.live) return;
+    const int b = wk.b, g = wk.g;
+    const int t0 = wk.tile * TMF;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, kgrp = lane >> 4;
     const int pad = p.pad >= 0 ? p.pad : K / 2;
@@ -277,7 +311,7 @@ hipError_t pc16_launch(const PosConvParams& p, hipStream_t s) {
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     hipError_t e = ensure_dynamic_lds<posconv16_kernel<T, DG, X3>>((int)lds);
     if (e != hipSuccess) return e;
-    dim3 grid((p.T + TMF - 1) / TMF, p.G, p.B);
+    dim3 grid((unsigned)(((p.T + TMF - 1) / TMF) * p.G * p.B));  // 1-D: pc_work maps it XCD-aware
     hipLaunchKernelGGL((posconv16_kernel<T, DG, X3>), grid, dim3(256), lds, s, p);
     return hipGetLastError();
 }

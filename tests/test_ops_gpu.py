@@ -224,9 +224,17 @@ def test_attention(dtype, T, rel):
         table = rng.standard_normal((H, 2 * rel + 1)).astype(np.float32)
         gate = (1 + rng.random((B, H, T))).astype(np.float32)
     qr = _round(qkv, dtype).astype(np.float64)
+    qdev = qkv
+    if dtype in ("bf16", "fp16"):
+        # the 16-bit kernels take q pre-scaled by log2(e) as well (base-2 scores, s3enc.h): round q * log2(e) to the operand
+        # type once, and let the reference see exactly that operand divided by log2(e)
+        log2e = 1.4426950408889634
+        qdev = qkv.copy()
+        qdev[:, :D] = _round(qkv[:, :D] * np.float32(log2e), dtype)
+        qr[:, :D] = qdev[:, :D].astype(np.float64) / log2e
     ref = _attention_ref(qr, valid, B, T, H, None if table is None else table.astype(np.float64),
                          None if gate is None else gate.astype(np.float64), R=rel)
-    dq = _dev(qkv, dtype)
+    dq = _dev(qdev, dtype)
     out = torch.zeros((B * T, D), device="cuda", dtype=dq.dtype)
     dvalid = torch.from_numpy(valid).cuda()
     dtable = _dev(table) if rel else None  # keep the device tensors alive across the call
