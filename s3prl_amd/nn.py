@@ -1,58 +1,89 @@
-"""Mirror of ``s3prl.nn.upstream`` for the MI355X path: ``S3PRLUpstream`` — padded ``(wavs, wavs_len)``
-in, ``(List[hs], List[hs_len])`` out, with the reference's length matching and re-padding (nn/upstream.py:166-231) —
-``Featurizer`` (re-exported from ``s3prl_amd.featurizer``) and ``UpstreamFeaturizer``, the two fused: the weighted sum
-runs as the encoder's epilogue, so only one ``(B, T, D)`` tensor ever leaves the library.
+"""The consumer side of the path on the MI355X experts:
 
-Differences from the reference, all on the cheap side: no probe forward at construction (layer count / hidden size
-come from the checkpoint's config), and the per-layer ``F.layer_norm`` of ``normalize=True`` is done by the library
-where it can be (fused path) — the default path applies ``F.layer_norm`` with torch exactly like the reference.
+* ``S3PRLUpstream`` — the interface of ``s3prl.nn.S3PRLUpstream`` (nn/upstream.py:102-231): padded ``(wavs, wavs_len)`` in,
+  ``(List[hs], List[hs_len])`` out, with the reference's frame-count contract: layer ``l`` of a batch padded to ``n`` samples
+  has ``ceil(n / stride_l)`` frames (an upstream that is off by rounding is trimmed, or its last frame repeated) and utterance
+  ``b`` owns the first ``ceil(len_b / stride_l)`` of them;
+* ``Featurizer`` (``s3prl.nn.Featurizer``, re-exported from ``s3prl_amd.featurizer``) and ``UpstreamFeaturizer``, the two
+  fused: the weighted sum runs as the encoder's epilogue, so only one ``(B, T, D)`` tensor ever leaves the library;
+* ``LegacyFeaturizer`` — the OLD interface, ``s3prl.upstream.interfaces.Featurizer`` (interfaces.py:134-272), the class
+  ``downstream/runner.py`` instantiates: ``feature_selection`` / ``layer_selection`` on the expert's result dict,
+  ``forward(paired_wavs, paired_features) -> List[Tensor]`` of un-padded per-utterance features.
+
+Differences from the reference, all on the cheap side: no probe forward at construction when the expert can answer from its
+checkpoint config (layer count / hidden size / stride), and the per-layer ``F.layer_norm`` of ``normalize=True`` is done by the
+library where it can be (fused path).
 """
 
 from __future__ import annotations
 
-from typing import List, Optional
+import sys
+from typing import Dict, List, Optional, Union
 
+import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from . import hub
-from .featurizer import Featurizer
+from .featurizer import Featurizer, _WeightedSum
 
 SAMPLE_RATE = 16000
-MIN_SECOND = 0.05  # nn/upstream.py:18-19
+MIN_SECOND = 0.05  # batches shorter than this are zero-extended before the encoder sees them (nn/upstream.py:18-19,183-192)
+TOLERABLE_SEQLEN_DIFF = 5  # interfaces.py:17: frames an upstream may be off before LegacyFeaturizer.tolist refuses
 
-__all__ = ["S3PRLUpstream", "Featurizer", "UpstreamFeaturizer"]
-
-
-def _match_length(xs: torch.Tensor, target_max_len: int) -> torch.Tensor:
-    """nn/upstream.py:150-164: trim, or repeat the last frame, when the frame count is off by rounding."""
-    n = xs.size(1)
-    if n > target_max_len:
-        assert n // target_max_len == 1, f"{n}, {target_max_len}"
-        xs = xs[:, :target_max_len, :]
-    elif n < target_max_len:
-        assert target_max_len // n == 1, f"{target_max_len}, {n}"
-        xs = torch.cat((xs, xs[:, -1:, :].repeat(1, target_max_len - n, 1)), dim=1)
-    return xs
+__all__ = ["S3PRLUpstream", "Featurizer", "UpstreamFeaturizer", "LegacyFeaturizer", "randomize_weights"]
 
 
-def _unpad(wavs: torch.Tensor, wavs_len: torch.Tensor):
-    """(padded (B, n) or (B, n, 1), lengths) -> (list of 1-D waveforms, lengths actually encoded, original lengths);
-    batches shorter than MIN_SECOND are zero-extended first (nn/upstream.py:183-192)."""
-    if wavs.dim() == 3:
-        wavs = wavs.squeeze(-1)
-    original = wavs_len
-    if int(max(original)) < MIN_SECOND * SAMPLE_RATE:
-        extra = int(MIN_SECOND * SAMPLE_RATE) - int(max(original))
-        wavs = torch.cat((wavs, wavs.new_zeros(wavs.size(0), extra)), dim=1)
-        wavs_len = wavs_len + extra
-    return [w[: int(n)] for w, n in zip(wavs, wavs_len)], wavs_len, original
+def _frames(n_samples, stride: int):
+    """frames of an n-sample signal at `stride`: ceil(n / stride) — int or tensor"""
+    return (n_samples + stride - 1) // stride if isinstance(n_samples, int) else torch.div(n_samples + stride - 1, stride, rounding_mode="floor")
+
+
+def _fit_frames(h: torch.Tensor, frames: int) -> torch.Tensor:
+    """(B, n, D) -> (B, frames, D): one gather with the frame index clamped to the last frame trims a surplus and repeats
+    the last frame over a deficit.  Only rounding-level mismatches are legal (fewer than a factor of two either way)."""
+    n = h.size(1)
+    if n == frames:
+        return h
+    assert 2 * min(n, frames) > max(n, frames), f"upstream returned {n} frames where {frames} were expected"
+    return h[:, torch.arange(frames, device=h.device).clamp_(max=n - 1), :]
+
+
+def _split_batch(wavs: torch.Tensor, wavs_len: torch.Tensor):
+    """padded (B, n) or (B, n, 1) + lengths -> (list of 1-D waveforms, lengths as encoded, lengths as given)."""
+    wavs = wavs.squeeze(-1) if wavs.dim() == 3 else wavs
+    given = wavs_len
+    floor = int(MIN_SECOND * SAMPLE_RATE)
+    short = floor - int(given.max())
+    if short > 0:  # every utterance grows by the same zeros, so the relative lengths survive
+        wavs = F.pad(wavs, (0, short))
+        wavs_len = given + short
+    return [w[: int(n)] for w, n in zip(wavs, wavs_len)], wavs_len, given
+
+
+def randomize_weights(weights: Dict[str, np.ndarray], seed: Optional[int] = None) -> Dict[str, np.ndarray]:
+    """What ``randomize_upstream`` does to a torch module (nn/upstream.py:27-35), on a checkpoint's tensor dict: vectors and
+    scalars are re-drawn from N(mean, std) of their own values, everything with two or more dimensions from Xavier-normal
+    (std = sqrt(2 / (fan_in + fan_out)), receptive field included)."""
+    rng = np.random.default_rng(seed)
+    out = {}
+    for name, w in weights.items():
+        w = np.asarray(w, dtype=np.float32)
+        if w.ndim < 2:
+            std = float(w.std(ddof=1)) if w.size > 1 else 0.0
+            out[name] = rng.normal(float(w.mean()) if w.size else 0.0, std if np.isfinite(std) else 0.0, size=w.shape).astype(np.float32)
+        else:
+            field = int(np.prod(w.shape[2:])) if w.ndim > 2 else 1
+            std = (2.0 / ((w.shape[0] + w.shape[1]) * field)) ** 0.5
+            out[name] = rng.normal(0.0, std, size=w.shape).astype(np.float32)
+    return out
 
 
 class S3PRLUpstream(nn.Module):
-    """``S3PRLUpstream(name, path_or_url=None, refresh=False, normalize=False, extra_conf=None, randomize=False)``
-    (nn/upstream.py:102-140) over ``s3prl_amd.hub``; ``forward(wavs, wavs_len) -> (all_hs, all_lens)``."""
+    """``S3PRLUpstream(name, path_or_url=None, refresh=False, normalize=False, extra_conf=None, randomize=False)`` over
+    ``s3prl_amd.hub``; ``forward(wavs, wavs_len) -> (all_hs, all_lens)``.  ``randomize=True`` re-draws every checkpoint
+    tensor (``randomize_weights``) before the weights are packed for the GPU."""
 
     @classmethod
     def available_names(cls, only_registered_ckpt: bool = False) -> List[str]:
@@ -61,23 +92,19 @@ class S3PRLUpstream(nn.Module):
     def __init__(self, name: str, path_or_url: str = None, refresh: bool = False, normalize: bool = False,
                  extra_conf: dict = None, randomize: bool = False):
         super().__init__()
-        if randomize:
-            raise NotImplementedError("randomize=True re-initialises a torch module's parameters; the MI355X experts hold "
-                                      "packed device weights — build the checkpoint with the weights you want instead")
-        conf = {"refresh": refresh, **(extra_conf or {})}
+        conf = dict(extra_conf or {}, refresh=refresh)
         if path_or_url is not None:
             conf["ckpt"] = path_or_url
         self.upstream = getattr(hub, name)(**conf)
+        if randomize:
+            if not hasattr(self.upstream, "randomize_"):
+                raise NotImplementedError(f"{name}: this upstream keeps no host copy of its weights to re-draw")
+            self.upstream.randomize_()
         self.normalize = normalize
         self._num_layers = int(self.upstream.num_layers)
         self._hidden_sizes = list(self.upstream.hidden_sizes)
         rates = self.upstream.get_downsample_rates("hidden_states")
-        if isinstance(rates, int):
-            self._downsample_rates = [rates] * self._num_layers
-        elif isinstance(rates, (tuple, list)):
-            self._downsample_rates = list(rates)
-        else:
-            raise ValueError
+        self._downsample_rates = list(rates) if isinstance(rates, (tuple, list)) else [int(rates)] * self._num_layers
 
     @property
     def num_layers(self) -> int:
@@ -92,21 +119,16 @@ class S3PRLUpstream(nn.Module):
         return self._hidden_sizes
 
     def forward(self, wavs: torch.FloatTensor, wavs_len: torch.LongTensor):
-        wavs_list, wavs_len, original = _unpad(wavs, wavs_len)
-        hidden_states = self.upstream(wavs_list)["hidden_states"]
-        assert isinstance(hidden_states, (list, tuple))
-        assert len(hidden_states) == self.num_layers, f"{len(hidden_states)}, {self.num_layers}"
-        max_wav_len = int(max(wavs_len))
+        wavs_list, encoded_len, given_len = _split_batch(wavs, wavs_len)
+        states = self.upstream(wavs_list)["hidden_states"]
+        assert isinstance(states, (list, tuple)) and len(states) == self.num_layers, \
+            f"the upstream returned {len(states)} states, {self.num_layers} were announced"
+        padded = int(encoded_len.max())
         all_hs, all_lens = [], []
-        for h, stride in zip(hidden_states, self.downsample_rates):
-            expected = len(range(0, max_wav_len, stride))
-            h = _match_length(h, expected)
-            assert h.size(1) == expected
-            h_len = torch.div(original - 1, stride, rounding_mode="floor") + 1
-            h = h[:, : int(max(h_len)), :]
-            if self.normalize:
-                h = F.layer_norm(h, h.shape[-1:])
-            all_hs.append(h)
+        for h, stride in zip(states, self.downsample_rates):
+            h_len = _frames(given_len, stride)
+            h = _fit_frames(h, _frames(padded, stride))[:, : int(h_len.max()), :]
+            all_hs.append(F.layer_norm(h, h.shape[-1:]) if self.normalize else h)
             all_lens.append(h_len)
         return all_hs, all_lens
 
@@ -137,7 +159,7 @@ class UpstreamFeaturizer(nn.Module):
 
     @torch.no_grad()
     def forward(self, wavs: torch.FloatTensor, wavs_len: torch.LongTensor, n_max: Optional[int] = None):
-        wavs_list, wavs_len, original = _unpad(wavs, wavs_len)
+        wavs_list, encoded_len, given_len = _split_batch(wavs, wavs_len)
         normalize = bool(self.upstream.normalize or self.featurizer.normalize)
         expert = self.upstream.upstream
         sel = getattr(expert, "feature_selection", None)
@@ -145,6 +167,82 @@ class UpstreamFeaturizer(nn.Module):
         if h.device != wavs.device:
             h = h.to(wavs.device)
         stride = self.upstream.downsample_rates[0]
-        h = _match_length(h, len(range(0, int(max(wavs_len)), stride)))
-        h_len = torch.div(original - 1, stride, rounding_mode="floor") + 1
-        return h[:, : int(max(h_len)), :], h_len
+        h_len = _frames(given_len, stride)
+        return _fit_frames(h, _frames(int(encoded_len.max()), stride))[:, : int(h_len.max()), :], h_len
+
+
+class LegacyFeaturizer(nn.Module):
+    """The interface of ``s3prl.upstream.interfaces.Featurizer`` (interfaces.py:134-272): built from an expert with a probe
+    forward, picks ``feature_selection`` out of the expert's result dict (``"hidden_states"`` when the key is unknown),
+    optionally one layer of it (``layer_selection``), else learns a softmax-weighted sum over the list — computed by
+    ``libs3enc`` (``csrc/featurizer.hip``, forward and the layer weights' backward) when the states are on the GPU — and
+    ``forward(paired_wavs, paired_features)`` returns the per-utterance features cut to ``round(len / downsample_rate)``
+    frames.  ``upstream_device`` is where the probe waveform is created (the experts move CPU waveforms to the GPU)."""
+
+    def __init__(self, upstream: nn.Module, feature_selection: str = "hidden_states", upstream_device: str = "cuda",
+                 layer_selection: Optional[int] = None, normalize: bool = False, **kwargs):
+        super().__init__()
+        self.name = "Featurizer"
+        upstream.eval()
+        probe = [torch.randn(SAMPLE_RATE).to(upstream_device)]
+        with torch.no_grad():
+            probe_out = upstream(probe)
+        if feature_selection not in probe_out:
+            if "hidden_states" not in probe_out:
+                print(f"[{self.name}] - Error: {feature_selection} is not a key of the upstream's result and neither is "
+                      f"\"hidden_states\"; available: {list(probe_out.keys())}", file=sys.stderr)
+                raise ValueError(feature_selection)
+            print(f"[{self.name}] - Warning: {feature_selection} is not a key of the upstream's result; using "
+                  f"\"hidden_states\"", file=sys.stderr)
+            feature_selection = "hidden_states"
+        self.feature_selection, self.layer_selection, self.normalize = feature_selection, layer_selection, bool(normalize)
+
+        feature = self._select_feature(probe_out)
+        if isinstance(feature, (list, tuple)):
+            self.layer_num = len(feature)
+            print(f"[{self.name}] - Take a list of {self.layer_num} features and weighted sum them.", file=sys.stderr)
+            self.weights = nn.Parameter(torch.zeros(self.layer_num))
+            feature = self._weighted_sum(list(feature))
+        self.output_dim = feature.size(-1)
+        if hasattr(upstream, "get_downsample_rates"):
+            self.downsample_rate = upstream.get_downsample_rates(feature_selection)
+        else:  # no static rate: derive it from the probe
+            self.downsample_rate = round(max(len(w) for w in probe) / feature.size(1))
+        print(f"[{self.name}] - The selected feature {feature_selection}'s downsample rate is {self.downsample_rate}",
+              file=sys.stderr)
+
+    def _select_feature(self, features: Dict[str, Union[torch.Tensor, list, dict]]):
+        feature = features.get(self.feature_selection)
+        if isinstance(feature, dict):
+            feature = list(feature.values())
+        if isinstance(feature, (list, tuple)):
+            if len(feature) == 1:
+                return feature[0]
+            if isinstance(self.layer_selection, int):
+                return feature[self.layer_selection]
+        return feature
+
+    def _weighted_sum(self, feature: List[torch.Tensor]) -> torch.Tensor:
+        assert self.layer_num == len(feature), (
+            f"the upstream returned {len(feature)} states, the weights were built for {self.layer_num} (an upstream with "
+            "layer drop returns a varying number of states: select one layer instead, e.g. last_hidden_state)")
+        norm_weights = F.softmax(self.weights, dim=-1)
+        if feature[0].is_cuda:  # the library's weighted sum (and, for training, its backward for the layer weights)
+            return _WeightedSum.apply(norm_weights, self.normalize, *feature)
+        stacked = torch.stack([f.float() for f in feature], dim=0)
+        if self.normalize:
+            stacked = F.layer_norm(stacked, stacked.shape[-1:])
+        return torch.tensordot(norm_weights.to(stacked.dtype), stacked, dims=1)
+
+    def tolist(self, paired_wavs: List[torch.Tensor], paired_feature: torch.Tensor) -> List[torch.Tensor]:
+        assert paired_feature.dim() == 3, "(batch_size, max_seq_len, feat_dim)"
+        lengths = [round(len(w) / self.downsample_rate) for w in paired_wavs]
+        off = abs(paired_feature.size(1) - round(max(len(w) for w in paired_wavs) / self.downsample_rate))
+        assert off < TOLERABLE_SEQLEN_DIFF, f"{off} >= {TOLERABLE_SEQLEN_DIFF}"
+        return [f[:n] for f, n in zip(paired_feature, lengths)]
+
+    def forward(self, paired_wavs: List[torch.Tensor], paired_features: Dict[str, Union[torch.Tensor, list, dict]]):
+        feature = self._select_feature(paired_features)
+        if isinstance(feature, (list, tuple)):
+            feature = self._weighted_sum(list(feature))
+        return self.tolist(paired_wavs, feature)

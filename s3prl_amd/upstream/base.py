@@ -51,6 +51,16 @@ class HipUpstreamExpert(torch.nn.Module):
         self.register_buffer("_device_probe", torch.zeros(1), persistent=False)
         return self
 
+    def randomize_(self, seed: Optional[int] = None):
+        """``S3PRLUpstream(randomize=True)`` (nn/upstream.py:27-35,119-120): re-draw every checkpoint tensor — vectors from
+        N(mean, std) of their own values, matrices / conv kernels Xavier-normal — and drop the packed GPU copies, so the
+        next forward builds the encoder from the new weights."""
+        from ..nn import randomize_weights
+
+        self._weights = randomize_weights(self._weights, seed)
+        self._encoders.clear()
+        return self
+
     # ---- what S3PRLUpstream learns from a probe forward (nn/upstream.py:124-140), without running one ----
     @property
     def num_layers(self) -> int:

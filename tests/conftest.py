@@ -19,7 +19,7 @@ def pytest_configure(config):
 def golden_names(encoder_only=True):
     """Encoder fixtures (hidden_states of a reference expert); ``feat_*`` fixtures pin the Featurizer / S3PRLUpstream."""
     names = sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz"))
-    return [n for n in names if not n.startswith("feat_")] if encoder_only else names
+    return [n for n in names if not n.startswith(("feat_", "legacyfeat_"))] if encoder_only else names
 
 
 def golden_meta(name):

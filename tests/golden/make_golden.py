@@ -283,6 +283,55 @@ def make_feat_case(name: str):
     print(f"{name}: {len(all_hs)} x {tuple(all_hs[0].shape)} -> feat {tuple(hs.shape)}, {os.path.getsize(path) / 1e3:.0f} kB")
 
 
+# The OLD Featurizer interface — s3prl.upstream.interfaces.Featurizer (interfaces.py:134-272), the class downstream/runner.py
+# instantiates — on a reference expert:  name -> (config, weight seed, wav seed, lengths, feature_selection, layer_selection,
+# normalize, weights seed).  Stored: the per-utterance features forward() returns, and the states they were computed from.
+LEGACY_FEAT_CASES = {
+    "legacyfeat_tiny_hubert_sum": ("tiny_hubert", 1, 61, [4000, 2345, 3111], "hidden_states", None, False, 11),
+    "legacyfeat_tiny_hubert_norm": ("tiny_hubert", 1, 62, [3999, 2345], "hidden_states", None, True, 12),
+    "legacyfeat_tiny_hubert_layer2": ("tiny_hubert", 1, 63, [4000, 3111], "hidden_states", 2, False, 13),
+    "legacyfeat_tiny_wavlm_last": ("tiny_wavlm_large", 8, 64, [4000, 2345, 3111], "last_hidden_state", None, False, 14),
+    "legacyfeat_tiny_hubert_unknown_key": ("tiny_hubert", 1, 65, [4000, 1234], "no_such_key", None, False, 15),
+}
+
+
+def make_legacy_feat_case(name: str):
+    import torch
+
+    cfg_name, wseed, xseed, lengths, fsel, lsel, norm, fseed = LEGACY_FEAT_CASES[name]
+    cfg = named_config(cfg_name)
+    weights = synth_weights(cfg, wseed)
+    wavs = synth_wavs(lengths, xseed)
+    _import_reference()
+    from s3prl.upstream.interfaces import Featurizer
+
+    with tempfile.TemporaryDirectory() as tmp:
+        expert, _ = build_reference_expert(cfg, weights, tmp)
+        expert.eval()
+        feat = Featurizer(expert, feature_selection=fsel, upstream_device="cpu", layer_selection=lsel, normalize=norm).eval()
+        fw = None
+        with torch.no_grad():
+            if hasattr(feat, "weights"):
+                fw = np.random.default_rng(fseed).standard_normal(len(feat.weights)).astype(np.float32)
+                feat.weights.copy_(torch.from_numpy(fw))
+            tw = [torch.from_numpy(w) for w in wavs]
+            result = expert(tw)
+            outs = feat(tw, result)
+    meta = dict(config=cfg_name, weight_seed=wseed, wav_seed=xseed, lengths=lengths, feature_selection=fsel,
+                resolved_selection=feat.feature_selection, layer_selection=lsel, normalize=norm, output_dim=int(feat.output_dim),
+                downsample_rate=int(feat.downsample_rate), num_states=len(result["hidden_states"]),
+                reference="s3prl 0.4.18 @ /root/reference: s3prl.upstream.interfaces.Featurizer on the reference expert, torch CPU fp32")
+    arrays = {f"out{b}": o.numpy() for b, o in enumerate(outs)}
+    for l, h in enumerate(result["hidden_states"]):
+        arrays[f"hs{l}"] = h.numpy()
+    if fw is not None:
+        arrays["feat_weights"] = fw
+    arrays["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    path = os.path.join(HERE, f"{name}.npz")
+    np.savez_compressed(path, **arrays)
+    print(f"{name}: {len(outs)} utterances -> {[tuple(o.shape) for o in outs]}, {os.path.getsize(path) / 1e3:.0f} kB")
+
+
 # Hugging Face checkpoints through the reference's hf_hubert / hf_wav2vec2 experts (upstream/hf_hubert/expert.py:12-41):
 # transformers' HubertModel / Wav2Vec2Model + Wav2Vec2FeatureExtractor on a checkpoint directory written by tests/hf_util.py
 # name -> (config, model_type, weight seed, wav seed, lengths, subsampling, dc, scale)
@@ -328,6 +377,9 @@ def make_hf_case(name: str):
 
 
 if __name__ == "__main__":
-    names = sys.argv[1:] or (list(CASES) + list(FEAT_CASES) + list(HF_CASES))
+    names = sys.argv[1:] or (list(CASES) + list(FEAT_CASES) + list(LEGACY_FEAT_CASES) + list(HF_CASES))
     for n in names:
+        if n in LEGACY_FEAT_CASES:
+            make_legacy_feat_case(n)
+            continue
         make_feat_case(n) if n in FEAT_CASES else (make_hf_case(n) if n in HF_CASES else make_case(n))
