@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define S3ENC_VERSION 3
+#define S3ENC_VERSION 4
 #define S3ENC_MAX_CONV 16
 #define S3ENC_MAX_RES 4 /* resolutions of a multires-HuBERT U-net: up to 3 rate pairs, 7 encoder blocks */
 
@@ -157,18 +157,6 @@ int s3enc_num_states(s3enc_handle h, int32_t selection, int32_t* n);
 int s3enc_forward_ex(s3enc_handle h, const float* const* wavs, const int64_t* lengths, int32_t B, int64_t n_max,
                      const s3enc_forward_opts* opts, void* out, int64_t layer_stride, void* stream);
 
-/* hipGraph replay of repeated forwards (off by default).  When on, a forward whose key — (B, n_max, selection, out_dtype,
- * out, layer_stride) — was already run eagerly once is captured into a hipGraph on its second occurrence and replayed from
- * the third on: the host then issues one table upload (waveform pointers, lengths, valid frames: the only per-call data
- * the kernels read) and ONE hipGraphLaunch instead of the ~300-600 kernel launches of a forward.  Meant for latency-bound
- * serving shapes (a few short utterances, where the GPU finishes a forward faster than the host can enqueue it); it needs
- * a non-NULL stream and the caller to reuse its output block.  Not used while profiling is enabled, layer events are set,
- * or with `featurize` (its weights are kernel arguments).  Graphs are discarded when a workspace is re-allocated (a larger
- * batch shape) and re-captured.  Replaces nothing in the reference (PyTorch eager launches every ATen op per call).
- * s3enc_graph_stats: graphs captured / forwards replayed so far. */
-int s3enc_set_graph_replay(s3enc_handle h, int32_t on);
-int s3enc_graph_stats(s3enc_handle h, int64_t* captures, int64_t* replays);
-
 /* Optional: `n` = encoder_layers+1 hipEvent_t handles (as void*); the following forwards record events[l] on the
  * launch stream as soon as hidden_states[l] is final, so a communication stream can start the all-gather of layer l
  * while later layers are still computing.  n = 0 clears.  The events stay owned by the caller. */
@@ -199,7 +187,10 @@ int s3enc_profile_read(s3enc_handle h, s3enc_profile_entry* entries, int32_t max
 int s3enc_debug_tap(s3enc_handle h, const char* name, float* host_out, int64_t max_elems, int64_t* n_elems);
 
 /* Process-wide tuning knobs (kernel-variant selection for A/B measurements; results are unchanged):
- *   "gemm_variant": bit 0 = 64-byte K stages (else 128), bit 1 = LDS-DMA staging, bit 2 = no XCD-aware tile order;
+ *   "gemm_variant": gemm.hip's 128x128 kernel: bit 0 = 64-byte K stages (else 128), bit 1 = LDS-DMA staging, bit 2 = no
+ *                   XCD-aware tile order;
+ *   "gemm32_big":   exact-fp32 tile kernel (gemmt.hip): 0 off (gemm.hip), 1 = tile height by shape (default), 2 / 3 / 4 / 5 =
+ *                   force 256 / 192 / 128 / 64 rows;  "gemm_x3_tile": the same for S3ENC_F32X3 (1 = only small shapes);
  *   "gemm16_big":   large-tile kernel of the 16-bit modes: 0 off, 1 = one workgroup per CU (256x256 or 192x256 tiles by CU
  *                   utilisation; 5 / 6 force either), 2 = 128x256, 4 = 128x256 with a 3-stage ring (two workgroups per
  *                   CU), 3 = chosen by shape (default). */

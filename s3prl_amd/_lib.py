@@ -21,7 +21,7 @@ FAMILY = {"hubert": 0, "wav2vec2": 1, "wavlm": 2, "distiller": 3, "multires_hube
 SEL_HIDDEN, SEL_LAYER_OUT, SEL_FFN_OUT = 0, 1, 2
 SELECTIONS = {None: SEL_HIDDEN, "hidden_states": SEL_HIDDEN, "fairseq_layers": SEL_LAYER_OUT,
               "fairseq_layers_before_residual": SEL_FFN_OUT}
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class S3Config(C.Structure):
@@ -74,8 +74,6 @@ _PROTOS = {
     "s3enc_num_states": (C.c_int, [_VP, _I32, C.POINTER(_I32)]),
     "s3enc_forward_padded": (C.c_int, [_VP, _VP, _I64, C.POINTER(_I64), _I32, _I64, _VP, _I64, _VP]),
     "s3enc_set_layer_events": (C.c_int, [_VP, C.POINTER(_VP), _I32]),
-    "s3enc_set_graph_replay": (C.c_int, [_VP, _I32]),
-    "s3enc_graph_stats": (C.c_int, [_VP, C.POINTER(_I64), C.POINTER(_I64)]),
     "s3enc_profile_enable": (C.c_int, [_VP, _I32]),
     "s3enc_profile_reset": (C.c_int, [_VP]),
     "s3enc_profile_read": (C.c_int, [_VP, C.POINTER(S3ProfileEntry), _I32, C.POINTER(_I32)]),

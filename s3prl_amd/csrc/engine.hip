@@ -12,7 +12,6 @@ namespace s3e {
 
 thread_local std::string g_err;
 int g_x3_pack_cache = 0;
-unsigned long g_devbuf_gen = 0;
 
 long conv_len(const s3enc_config& c, long n, int upto /*exclusive*/) {
     for (int i = 0; i < upto; ++i) n = n >= c.conv_kernel[i] ? (n - c.conv_kernel[i]) / c.conv_stride[i] + 1 : 0;
@@ -547,89 +546,7 @@ struct Sink {
     }
 };
 
-// Stream capture of one forward's launches into slot->exec.  Ends the capture on every exit path (a failed forward must
-// not leave the caller's stream capturing); finish() instantiates and launches the graph — the capture pass itself
-// executed nothing.
-struct CaptureGuard {
-    s3enc_encoder* e = nullptr;
-    hipStream_t st = nullptr;
-    s3enc_encoder::GraphSlot* slot = nullptr;  // the key of this forward when graph replay is on, else null
-    bool active = false;
-    ~CaptureGuard() {
-        if (!active) return;
-        hipGraph_t g = nullptr;
-        (void)hipStreamEndCapture(st, &g);
-        if (g) (void)hipGraphDestroy(g);
-        (void)hipGetLastError();
-        slot->seen = -(1 << 30);  // this key stays eager from now on ...
-        e->capture_aborted = true;  // ... starting with a re-run of this very forward (forward_impl)
-    }
-    int finish() {
-        if (!slot) return 0;
-        if (!active) {
-            slot->seen += 1;
-            return 0;
-        }
-        active = false;
-        hipGraph_t g = nullptr;
-        hipGraphExec_t ex = nullptr;
-        hipError_t err = hipStreamEndCapture(st, &g);
-        if (err == hipSuccess && g) {
-            err = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
-            (void)hipGraphDestroy(g);
-        }
-        if (err != hipSuccess || !ex) {  // nothing ran: forward_impl re-runs this forward eagerly, the key stays eager
-            (void)hipGetLastError();
-            slot->seen = -(1 << 30);
-            e->capture_aborted = true;
-            return fail(std::string("graph capture failed: ") + hipGetErrorString(err));
-        }
-        slot->exec = ex;
-        slot->gen = g_devbuf_gen;
-        e->graph_captures += 1;
-        HIP_TRY(hipGraphLaunch(ex, st));
-        return 0;
-    }
-};
-int forward_once(s3enc_handle e, const float* const* wav_ptrs_host, const int64_t* lengths, int32_t B, int64_t n_max_in,
-                 const FwdOpts& fo, void* out, int64_t layer_stride, hipStream_t st);
-
 int forward_impl(s3enc_handle e, const float* const* wav_ptrs_host, const int64_t* lengths, int32_t B, int64_t n_max_in,
-                 const FwdOpts& fo, void* out, int64_t layer_stride, hipStream_t st) {
-    e->capture_aborted = false;
-    const bool fence = e->graphs_on && !st;
-    hipStream_t caller = st;
-    if (fence) {
-        DeviceGuard dg(e->device);
-        if (!e->graph_stream) {
-            HIP_TRY(hipStreamCreateWithFlags(&e->graph_stream, hipStreamNonBlocking));
-            HIP_TRY(hipEventCreateWithFlags(&e->graph_ev_in, hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&e->graph_ev_out, hipEventDisableTiming));
-        }
-        st = e->graph_stream;
-        HIP_TRY(hipEventRecord(e->graph_ev_in, caller));
-        HIP_TRY(hipStreamWaitEvent(st, e->graph_ev_in, 0));
-    }
-    struct Rejoin {  // whatever was enqueued on the private stream (also by a forward that failed half-way) is waited for
-        s3enc_encoder* e;
-        hipStream_t caller;
-        bool on;
-        ~Rejoin() {
-            if (!on) return;
-            DeviceGuard dg(e->device);
-            if (hipEventRecord(e->graph_ev_out, e->graph_stream) == hipSuccess) (void)hipStreamWaitEvent(caller, e->graph_ev_out, 0);
-        }
-    } rejoin{e, caller, fence};
-    int rc = forward_once(e, wav_ptrs_host, lengths, B, n_max_in, fo, out, layer_stride, st);
-    if (rc && e->capture_aborted) {
-        // the capture pass of a graph replay hit something it could not record: nothing was executed — run the forward eagerly
-        e->capture_aborted = false;
-        rc = forward_once(e, wav_ptrs_host, lengths, B, n_max_in, fo, out, layer_stride, st);
-    }
-    return rc;
-}
-
-int forward_once(s3enc_handle e, const float* const* wav_ptrs_host, const int64_t* lengths, int32_t B, int64_t n_max_in,
                  const FwdOpts& fo, void* out, int64_t layer_stride, hipStream_t st) {
     const s3enc_config& c = e->cfg;
     const int C = c.conv_dim, D = c.embed_dim, F = c.ffn_dim, H = c.heads, NL = c.encoder_layers;
@@ -764,50 +681,6 @@ int forward_once(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
         ffnbuf = (ffn_tap && (fo.featurize || fo.out_dtype != F32)) ? wb.take((size_t)M * D * 4) : nullptr;
         if (!pass) HIP_TRY(e->ws.ensure_on_stream(wb.off + 4096, st));
     }
-    // ---- hipGraph replay (opt-in): everything below only enqueues kernels whose arguments are functions of the key ----
-    CaptureGuard cap;
-    cap.e = e;
-    cap.st = st;
-    if (e->graphs_on && st && !e->prof && e->layer_events.empty() && !fo.featurize) {
-        s3enc_encoder::GraphSlot* slot = nullptr;
-        for (auto& g : e->graphs)
-            if (g.B == B && g.n_max == n_max && g.selection == fo.selection && g.out_dtype == fo.out_dtype && g.out == out &&
-                g.stride == (long)layer_stride)
-                slot = &g;
-        if (!slot) {
-            if (e->graphs.size() >= 16) {  // evict the least recently used
-                size_t lru = 0;
-                for (size_t i = 1; i < e->graphs.size(); ++i)
-                    if (e->graphs[i].used < e->graphs[lru].used) lru = i;
-                if (e->graphs[lru].exec) (void)hipGraphExecDestroy(e->graphs[lru].exec);
-                e->graphs.erase(e->graphs.begin() + lru);
-            }
-            e->graphs.emplace_back();
-            slot = &e->graphs.back();
-            slot->B = B;
-            slot->n_max = n_max;
-            slot->selection = fo.selection;
-            slot->out_dtype = fo.out_dtype;
-            slot->out = out;
-            slot->stride = (long)layer_stride;
-        }
-        slot->used = ++e->graph_clock;
-        if (slot->exec && slot->gen != g_devbuf_gen) {  // a workspace moved since the capture
-            (void)hipGraphExecDestroy(slot->exec);
-            slot->exec = nullptr;
-        }
-        if (slot->exec) {
-            e->graph_replays += 1;
-            HIP_TRY(hipGraphLaunch(slot->exec, st));
-            return 0;
-        }
-        cap.slot = slot;
-        if (slot->seen >= 1) {
-            hipError_t ce = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
-            if (ce == hipSuccess) cap.active = true;
-            else (void)hipGetLastError();  // e.g. a stream that cannot capture: stay eager
-        }
-    }
     e->taps.clear();
 
     Sink sink{e, st, fo.featurize ? 2 : (fo.out_dtype != F32 ? 1 : 0), out, (long)layer_stride, dt, M, D, fo.w, fo.feat_norm};
@@ -937,8 +810,7 @@ int forward_once(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
     if (mr) {
         std::vector<const int*> dv(plan.blocks.size(), d_valid);
         for (size_t bi = 1; bi < plan.blocks.size(); ++bi) dv[bi] = (const int*)(d_tbl + (size_t)B * 20) + (bi - 1) * (size_t)B;
-        if (multires_tail(e, st, B, plan, dv, xproj, out, (long)layer_stride, fo)) return 1;
-        return cap.finish();
+        return multires_tail(e, st, B, plan, dv, xproj, out, (long)layer_stride, fo) ? 1 : 0;
     }
     // positional conv + residual; hidden_states[0]
     float* x_cur;          // the fp32 residual stream entering the layer loop
@@ -1243,7 +1115,7 @@ int forward_once(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
             HIP_TRY(sink.done(si));
         }
     }
-    return cap.finish();
+    return 0;
 }
 }  // namespace
 
@@ -1304,25 +1176,6 @@ int s3enc_set_layer_events(s3enc_handle h, void* const* events, int32_t n) {
     if (!events || n < h->cfg.encoder_layers || n > num_states(h->cfg, S3ENC_SEL_HIDDEN))
         return fail("s3enc_set_layer_events: pass one event per state of the selection the forwards will use");
     h->layer_events.assign((hipEvent_t const*)events, (hipEvent_t const*)events + n);
-    return 0;
-}
-
-int s3enc_set_graph_replay(s3enc_handle h, int32_t on) {
-    if (!h) return fail("null handle");
-    DeviceGuard dg(h->device);
-    h->graphs_on = on != 0;
-    if (!on) {
-        HIP_TRY(hipDeviceSynchronize());
-        for (auto& g : h->graphs)
-            if (g.exec) (void)hipGraphExecDestroy(g.exec);
-        h->graphs.clear();
-    }
-    return 0;
-}
-int s3enc_graph_stats(s3enc_handle h, int64_t* captures, int64_t* replays) {
-    if (!h || !captures || !replays) return fail("s3enc_graph_stats: null argument");
-    *captures = h->graph_captures;
-    *replays = h->graph_replays;
     return 0;
 }
 

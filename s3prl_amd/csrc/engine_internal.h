@@ -1,6 +1,6 @@
 // engine_internal.h — what the translation units of the engine share: error reporting, device buffers, the weight containers,
 // the handle (struct s3enc_encoder), per-kernel profiling, the workspace allocator and the multires-HuBERT plan.
-//   engine.hip    s3enc_create (weight packing), the single-resolution forward schedule, graph replay, the handle's C ABI
+//   engine.hip    s3enc_create (weight packing), the single-resolution forward schedule, the handle's C ABI
 //   multires.hip  the multires-HuBERT U-net behind post_extract_proj
 //   ops.hip       single-kernel entry points (s3enc_op_*), the weighted sum, fbank, tuning keys
 #pragma once
@@ -65,10 +65,6 @@ inline float h_from16(uint16_t v, int dtype) {
     return (float)h;
 }
 
-// bumped by every (re)allocation of a DevBuf: a captured forward graph bakes workspace addresses in, so a graph made
-// under an older generation is discarded and re-captured (s3enc_set_graph_replay)
-extern unsigned long g_devbuf_gen;
-
 struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
@@ -92,7 +88,6 @@ struct DevBuf {
         }
         hipError_t e = hipMalloc(&p, n);
         if (e == hipSuccess) bytes = n;
-        ++g_devbuf_gen;
         return e;
     }
     // Growth on the forward path, ordered on `st` instead of synchronising the device: the old block is released with
@@ -118,7 +113,6 @@ struct DevBuf {
         }
         p = np;
         bytes = want;
-        ++g_devbuf_gen;
         return hipSuccess;
     }
 };
@@ -259,30 +253,6 @@ struct s3enc_encoder {
     std::vector<AdapterW> mr_adapters;  // downsample_modules[0..R-2], then upsample_modules[0..R-2]
     DevBuf ws_mr;                       // activation workspace of the U-net behind post_extract_proj
 
-    // hipGraph replay of repeated forwards (s3enc_set_graph_replay): one executable graph per (batch shape, state
-    // selection, output block).  The per-call data — waveform pointers, lengths, valid frames — reach the kernels through
-    // the device table that is uploaded BEFORE the graph is launched, so a replay is: table upload + one hipGraphLaunch.
-    struct GraphSlot {
-        int B = 0;
-        long n_max = 0;
-        int selection = 0, out_dtype = 0;
-        const void* out = nullptr;
-        long stride = 0;
-        hipGraphExec_t exec = nullptr;
-        unsigned long gen = 0;  // g_devbuf_gen the graph was captured under
-        int seen = 0;           // successful eager forwards with this key (the first one sizes workspaces and LDS attributes)
-        unsigned long used = 0;
-    };
-    int graphs_on = 0;
-    std::vector<GraphSlot> graphs;
-    unsigned long graph_clock = 0;
-    long graph_replays = 0, graph_captures = 0;
-    bool capture_aborted = false;
-    // the NULL (legacy default) stream cannot be captured: with graph replay on, a forward submitted to it runs on this
-    // private stream instead, fenced by events on both sides (ordered after the caller's earlier work, before its later work)
-    hipStream_t graph_stream = nullptr;
-    hipEvent_t graph_ev_in = nullptr, graph_ev_out = nullptr;
-
     DevBuf ws;      // activation workspace
     DevBuf small;   // tables, stats
     void* pinned = nullptr;  // host staging ring
@@ -315,11 +285,6 @@ struct s3enc_encoder {
             (void)hipEventDestroy(r.b);
         }
         for (auto ev : ev_pool) (void)hipEventDestroy(ev);
-        for (auto& g : graphs)
-            if (g.exec) (void)hipGraphExecDestroy(g.exec);
-        if (graph_ev_in) (void)hipEventDestroy(graph_ev_in);
-        if (graph_ev_out) (void)hipEventDestroy(graph_ev_out);
-        if (graph_stream) (void)hipStreamDestroy(graph_stream);
         for (int i = 0; i < RING; ++i)
             if (slot_ev[i]) (void)hipEventDestroy(slot_ev[i]);
         if (pinned) (void)hipHostFree(pinned);

@@ -13,8 +13,9 @@
 //               (128 FLOP per staged byte) — the default for every shape since the 16-bit epilogues store 16 bytes per
 //               lane (round 2: q|k|v 64 vs 72 us, fc1 99 vs 104 us against mode 4);
 //       mode 4  128x256 tile, ring of 3 stages of 32 k with two K-steps in flight, two workgroups per CU that hide
-//               each other's barriers and epilogues — kept as a tuning option (`gemm16_big` = 4);
-//       modes 7-9: the phase-pipelined kernel of gemm16p.hip.
+//               each other's barriers and epilogues — kept as a tuning option (`gemm16_big` = 4).
+//     (Round 2's phase-pipelined variant, gemm16p.hip — staggered wave rows, region-granular DMA ring — measured equal or
+//     slower on every shape and was removed in round 3.)
 //     The DMA pieces are interleaved with the MFMA steps (an LDS-DMA instruction costs 60-180 issue cycles).  LDS rows
 //     are XOR-swizzled through the per-lane SOURCE address (the DMA image is lane-linear) so every ds_read_b128
 //     fragment read is bank-conflict free — same layout as gemm.hip.
@@ -382,7 +383,6 @@ hipError_t launch_gemm16_big(int dtype, const GemmParams& p, hipStream_t stream)
         // round 1 preferred for K = 768 when the epilogue's 8-byte stores were the longer part of a tile
         mode = 1;
     }
-    if (mode >= 7) return launch_gemm16_phased(dtype, mode, p, stream);  // gemm16p.hip
     return dtype == BF16 ? big_mode<bf16_tag>(mode, p, stream) : big_mode<f16_tag>(mode, p, stream);
 }
 

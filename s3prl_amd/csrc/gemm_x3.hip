@@ -229,10 +229,7 @@ bool gemm_x3_eligible(const GemmParams& p) {
     return p.M >= 128 && p.N >= 128;
 }
 
-int g_gemm_x3_mode = 0;
-
 hipError_t launch_gemm_x3(const GemmParams& p, hipStream_t stream) {
-    if (g_gemm_x3_mode == 1) return launch_gemm_x3_phased(p, stream);
     // 256- or 192-row tiles, whichever leaves fewer idle CU-rounds (see gemm16.hip)
     const long nt = (p.N + 255) / 256;
     const long t256 = ((p.M + 255) / 256) * nt * p.batches, t192 = ((p.M + 191) / 192) * nt * p.batches;

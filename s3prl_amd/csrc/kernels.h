@@ -47,11 +47,6 @@ void pack_x3(const float* w, long N, long K, std::vector<uint16_t>& out);  // ho
 extern int g_gemm16_big;
 bool gemm16_big_eligible(int dtype, const GemmParams& p);
 hipError_t launch_gemm16_big(int dtype, const GemmParams& p, hipStream_t stream);
-// gemm16p.hip: phase-pipelined 256x256 tile (staggered wave rows, region-granular LDS-DMA ring, counted vmcnt)
-extern int g_gemm16_probe;
-extern int g_gemm_x3_mode;  // 0: gemm_x3.hip (two-stage lockstep), 1: the phased schedule of gemm16p.hip
-hipError_t launch_gemm_x3_phased(const GemmParams& p, hipStream_t stream);
-hipError_t launch_gemm16_phased(int dtype, int mode, const GemmParams& p, hipStream_t stream);
 // gemmt.hip: (256 | 192 | 128 | 64) x 128 tiles, several independent workgroups per CU; fp32 results bit-identical to
 // gemm.hip's kernel.  Tuning keys: 0 off, 1 = tile height by shape, 2..5 = force 256 / 192 / 128 / 64 rows
 extern int g_gemm32_big;   // fp32 mode (default 1)

@@ -27,7 +27,7 @@ int s3enc_set_tuning(const char* key, int32_t value) {
         return 0;
     }
     if (!strcmp(key, "gemm16_big")) {
-        if (value < 0 || value > 9) return fail("gemm16_big must be 0..9");
+        if (value < 0 || value > 6) return fail("gemm16_big must be 0..6");
         g_gemm16_big = value;
         return 0;
     }
@@ -38,16 +38,6 @@ int s3enc_set_tuning(const char* key, int32_t value) {
     }
     if (!strcmp(key, "x3_pack_cache")) {
         g_x3_pack_cache = value != 0;
-        return 0;
-    }
-    if (!strcmp(key, "gemm_x3_mode")) {
-        if (value < 0 || value > 1) return fail("gemm_x3_mode must be 0..1");
-        g_gemm_x3_mode = value;
-        return 0;
-    }
-    if (!strcmp(key, "gemm16_probe")) {
-        if (value < 0 || value > 6) return fail("gemm16_probe must be 0..6");
-        g_gemm16_probe = value;
         return 0;
     }
     return fail(std::string("s3enc_set_tuning: unknown key '") + key + "'");

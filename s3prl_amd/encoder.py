@@ -190,16 +190,6 @@ class HipEncoder:
             self._events = evs
         return self._events
 
-    def graph_replay(self, on: bool = True):
-        """Replay repeated forwards from a captured hipGraph (``s3enc_set_graph_replay``): for latency-bound serving shapes.
-        A forward is replayed when its batch shape AND its output tensor (pass ``out=``) repeat."""
-        _lib.check(self._lib.s3enc_set_graph_replay(self._h, int(bool(on))), "s3enc_set_graph_replay")
-
-    def graph_stats(self):
-        c, r = C.c_int64(), C.c_int64()
-        _lib.check(self._lib.s3enc_graph_stats(self._h, C.byref(c), C.byref(r)))
-        return {"captures": c.value, "replays": r.value}
-
     # ---- measurement / test hooks ----
     def profile_enable(self, on=True):
         """True / 1: HIP events around every kernel; 2: only around the GEMM launches; False / 0: off."""

@@ -59,11 +59,11 @@ def test_gemm_variants(dtype, case, variant):
         _lib.check(lib.s3enc_set_tuning(b"gemm_variant", 3))
 
 
-@pytest.mark.parametrize("mode", [1, 2, 4, 5, 6, 7, 8, 9, 0])
+@pytest.mark.parametrize("mode", [1, 2, 4, 5, 6, 0])
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("case", ["big_plain", "big_conv", "big_epilogue", "big_edge"])
 def test_gemm16_big_tiles(dtype, case, mode):
-    """The large-tile LDS-DMA kernels of the 16-bit modes (gemm16.hip; mode 7 = the phase-pipelined gemm16p.hip): 256x256 (mode 1) and 128x256 (mode 2) tiles on
+    """The large-tile LDS-DMA kernels of the 16-bit modes (gemm16.hip): 256x256 (mode 1) and 128x256 (mode 2) tiles on
     shapes that span several tiles with ragged M / N edges, overlapping conv rows, batches and the full epilogue;
     mode 0 runs the same shapes through the 128x128 kernel."""
     from s3prl_amd import _lib
@@ -282,9 +282,9 @@ def test_posconv(dtype, shape):
     assert err < TOL[dtype], f"posconv {dtype}/{shape}: rel-err {err:.3e}"
 
 
-@pytest.mark.parametrize("schedule", [0, 1])
+@pytest.mark.parametrize("tile", [0, 1, 2, 4])
 @pytest.mark.parametrize("case", ["big_plain", "big_conv", "big_epilogue", "x3_long"])
-def test_gemm_x3_split_precision(case, schedule):
+def test_gemm_x3_split_precision(case, tile):
     """gemm_x3.hip: fp32 operands, every product rebuilt from three bf16 MFMAs (hi*hi + lo*hi + hi*lo).  Against the
     float64 product of the UNROUNDED fp32 operands the error must sit at the 1e-5 level (vs 3e-3 for plain bf16 and
     1e-6 for the exact kernel), on multi-tile shapes with ragged edges, overlapping conv rows and the full epilogue."""
@@ -292,7 +292,8 @@ def test_gemm_x3_split_precision(case, schedule):
     from s3prl_amd import _lib
 
     lib = _lib.load()
-    _lib.check(lib.s3enc_set_tuning(b"gemm_x3_mode", schedule))  # 0: gemm_x3.hip, 1: the phased schedule (gemm16p.hip)
+    # 0: gemm_x3.hip's lock-step 256x256 tile; 1: the default choice; 2 / 4: the 256 / 128-row tile kernel of gemmt.hip
+    _lib.check(lib.s3enc_set_tuning(b"gemm_x3_tile", tile))
     rng = np.random.default_rng(zlib.crc32(f"x3/{case}".encode()))
     act, use_res, use_lim = 0, False, False
     Cc, Lin = 128, 1101
@@ -330,7 +331,7 @@ def test_gemm_x3_split_precision(case, schedule):
     out = torch.full((batches, M, N), float("nan"), device="cuda")
     rc = lib.s3enc_op_gemm(3, _ptr(dA), lda, a_bs, _ptr(dW), _ptr(dbias), M, N, K, batches, act,
                            _ptr(dres) if use_res else None, _ptr(dlim) if use_lim else None, _ptr(out), None, N, M * N, None)
-    _lib.check(lib.s3enc_set_tuning(b"gemm_x3_mode", 0))
+    _lib.check(lib.s3enc_set_tuning(b"gemm_x3_tile", 1))
     _lib.check(rc, "s3enc_op_gemm x3")
     got = out.cpu().numpy()
     assert np.isfinite(got).all()

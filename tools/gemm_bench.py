@@ -37,13 +37,13 @@ def _fill(n, scale=1.0):
 
 
 def run(dtype, variants=None, rounds=5, shapes=None, reps=10):
-    x3 = dtype == "fp32x3"  # variants: gemm_x3_mode 0 / 1
+    x3 = dtype == "fp32x3"  # variants: gemm_x3_tile 0 (gemm_x3.hip) / 2..5 (gemmt.hip tile heights)
     big = dtype not in ("fp32", "fp32x3")
     if x3 and variants is None:
-        variants = (0, 1)
+        variants = (0, 2, 4)
     if variants is None:
         # 16-bit modes: the large-tile kernel's configurations (gemm16_big; 0 = the 128x128 kernel); fp32: staging variants
-        variants = (0, 1, 4, 5, 6, 7) if big else (1, 3, 0, 2)
+        variants = (0, 1, 4, 5, 6) if big else (1, 3, 0, 2)
     td = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16, "fp32x3": torch.float32}[dtype]
     _lib.check(lib.s3enc_set_tuning(b"x3_pack_cache", 1 if x3 else 0))
     print(f"== {dtype}")
@@ -69,10 +69,9 @@ def run(dtype, variants=None, rounds=5, shapes=None, reps=10):
         for r in range(rounds + 1):
             for v in variants:
                 if x3:
-                    _lib.check(lib.s3enc_set_tuning(b"gemm_x3_mode", v))
-                elif big:  # v >= 100: timing probe (v - 100) of the phase-pipelined kernel (mode 7); results are garbage
-                    _lib.check(lib.s3enc_set_tuning(b"gemm16_big", 7 if v >= 100 else v))
-                    _lib.check(lib.s3enc_set_tuning(b"gemm16_probe", v - 100 if v >= 100 else 0))
+                    _lib.check(lib.s3enc_set_tuning(b"gemm_x3_tile", v))
+                elif big:
+                    _lib.check(lib.s3enc_set_tuning(b"gemm16_big", v))
                 else:
                     _lib.check(lib.s3enc_set_tuning(b"gemm_variant", v))
                 torch.cuda.synchronize()

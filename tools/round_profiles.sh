@@ -27,7 +27,6 @@ python bench.py --gpus 2 --backend gloo --gather layers16 --dtype bf16 --steps 5
 for d in fp32 fp32x3 bf16; do
   python bench.py --model multires_hubert_base --dtype $d --no-cpu-baseline --steps 40 --warmup 3 > $out/bench_multires_hubert_base_$d.json 2>/dev/null
 done
-python tools/graph_latency.py > $out/graph_replay.md 2>/dev/null
 python tools/gemm_yardstick.py > $out/gemm_yardstick.md 2>/dev/null          # vendor BLAS beside the library's GEMMs (yardstick only)
 for m in mfma_peak gemm_loop_probe; do                                        # matrix-pipe ceilings and the fp32 loop's ingredients
   [ -x tools/micro/$m ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 tools/micro/$m.hip -o tools/micro/$m 2>/dev/null
