@@ -117,6 +117,9 @@ def parse_args(argv=None):
                     help="mixed-length batch (BASELINE configs[4] recipe): utterance 0 has --secs, the rest "
                          "randint(1 s, --secs), seed 1234; frames are counted per utterance (sum of T_i)")
     ap.add_argument("--gather", default="layers", choices=["layers", "layers16", "featurized", "none"])
+    ap.add_argument("--exchange-via", default="torch", choices=["torch", "cabi"],
+                    help="who issues the per-layer RCCL all-gathers: torch.distributed (default) or the library's own "
+                         "s3enc_comm_* entry points (the path a non-Python binder uses; needs --backend nccl)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baseline leg (the parity leg still runs)")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=INT",
@@ -265,6 +268,12 @@ def main():
     elif gather == "featurized":
         gathered = torch.empty((world * B, T, D), dtype=torch.float32, device=dev)
 
+    cabi = None
+    if world > 1 and args.exchange_via == "cabi" and gather in ("layers", "layers16"):
+        from s3prl_amd.parallel import RcclComm
+
+        cabi = RcclComm(device=dev.index)  # the 128-byte RCCL id travels over the existing process group
+
     def step(exchange=True):
         if world == 1:
             return expert(wavs)  # UpstreamExpert.forward: the metric as SURVEY §8d defines it
@@ -280,7 +289,10 @@ def main():
             if exchange and gather != "none":
                 # one all-gather per layer (hidden_states[l] stays a contiguous (B_global, T, D) block), issued on a
                 # side stream as soon as layer l is final so it overlaps the remaining layers' compute
-                gather_layers(hs, overlap_events=events, out=gathered)
+                if cabi is not None:
+                    cabi.gather_layers(hs, overlap_events=events, out=gathered)
+                else:
+                    gather_layers(hs, overlap_events=events, out=gathered)
             return hs
 
     def timed(k, exchange=True, profile=False):

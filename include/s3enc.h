@@ -12,7 +12,9 @@
  *   - pointers documented "device" are HIP device pointers on the handle's GPU; "host" are host pointers.
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Work is enqueued
  *     asynchronously on it and ordered with the caller's own work on that stream.
- *   - a handle is not re-entrant; distinct handles are independent (one per GPU / per process rank).
+ *   - a handle is not re-entrant and serves ONE stream at a time: its workspaces are grown and released in the order of the
+ *     stream of the call that grows them, so before moving a handle to another stream the caller orders that stream after
+ *     the handle's last forward (an event, or a synchronise).  Distinct handles are independent (one per GPU / rank / stream).
  *   - there is no CPU fallback: without a gfx950 device s3enc_create fails.
  */
 #ifndef S3ENC_H
@@ -162,6 +164,29 @@ int s3enc_forward_ex(s3enc_handle h, const float* const* wavs, const int64_t* le
  * while later layers are still computing.  n = 0 clears.  The events stay owned by the caller. */
 int s3enc_set_layer_events(s3enc_handle h, void* const* events, int32_t n);
 
+/* ---- multi-GPU: the exchange step of the data-parallel path ---------------------------------------
+ * One rank per GPU (process or thread).  Rank r encodes its contiguous block of the batch padded to the GLOBAL n_max
+ * (s3enc_forward's n_max argument — the only coupling between utterances) into a (states, shard, T, D) slab; the slabs are
+ * re-assembled into (states, world * shard, T, D), rank order = input order, with one RCCL all-gather per state over xGMI.
+ * Replaces: nothing in the reference's upstream path (run_downstream.py:166-168 only wraps trainable upstreams in DDP);
+ * it is what torch.distributed.all_gather_into_tensor does for the Python binding (s3prl_amd/parallel.py).
+ *   s3enc_comm_unique_id   rank 0 draws the 128-byte RCCL id and hands it to the other ranks by any side channel
+ *   s3enc_comm_init_rank   collective over all ranks; `device` = the rank's GPU.  world = 1 is valid (gathers are copies).
+ *   s3enc_comm_allgather_states
+ *       send / recv: device; state l is `bytes_per_state` bytes at send + l * send_state_stride, and lands as rank r's block
+ *       at recv + l * recv_state_stride + r * bytes_per_state (strides in BYTES; recv_state_stride >= world * bytes_per_state).
+ *       ready_events: NULL, or n_states hipEvent_t (as void*) — the events given to s3enc_set_layer_events: the gather of
+ *       state l then starts as soon as the encoder has recorded event l, on the communicator's own stream, while the
+ *       remaining layers still compute.  On return the gathers are enqueued and `stream` is ordered after the last of them. */
+typedef struct s3enc_comm_s* s3enc_comm;
+int s3enc_comm_version(int32_t* version); /* RCCL's version code; fails (with the reason) when librccl cannot be loaded */
+int s3enc_comm_unique_id(void* id128);
+int s3enc_comm_init_rank(const void* id128, int32_t world, int32_t rank, int32_t device, s3enc_comm* out);
+int s3enc_comm_info(s3enc_comm c, int32_t* world, int32_t* rank);
+int s3enc_comm_allgather_states(s3enc_comm c, const void* send, int64_t send_state_stride, void* recv, int64_t recv_state_stride,
+                                int32_t n_states, int64_t bytes_per_state, void* const* ready_events, void* stream);
+int s3enc_comm_destroy(s3enc_comm c);
+
 /* Same, for a zero-padded (B, row_stride) device buffer (what pad_sequence builds, hubert/expert.py:66). */
 int s3enc_forward_padded(s3enc_handle h, const float* pcm, int64_t row_stride, const int64_t* lengths, int32_t B,
                          int64_t n_max, float* out, int64_t layer_stride, void* stream);
@@ -195,6 +220,9 @@ int s3enc_debug_tap(s3enc_handle h, const char* name, float* host_out, int64_t m
  *                   utilisation; 5 / 6 force either), 2 = 128x256, 4 = 128x256 with a 3-stage ring (two workgroups per
  *                   CU), 3 = chosen by shape (default). */
 int s3enc_set_tuning(const char* key, int32_t value);
+/* The same keys for ONE handle: the handle starts from the process-wide values as they are at the first call and keeps its own
+ * copy from then on; its forwards use that copy (per calling thread), other handles and the s3enc_op_* entry points do not. */
+int s3enc_set_handle_tuning(s3enc_handle h, const char* key, int32_t value);
 
 /* ---- single-kernel entry points (parity tests of each HIP kernel against the oracle) -------------------
  * All pointers are device pointers; dtype is S3ENC_F32/BF16/F16 for the 16-bit-capable operands

@@ -78,6 +78,13 @@ _PROTOS = {
     "s3enc_profile_reset": (C.c_int, [_VP]),
     "s3enc_profile_read": (C.c_int, [_VP, C.POINTER(S3ProfileEntry), _I32, C.POINTER(_I32)]),
     "s3enc_debug_tap": (C.c_int, [_VP, C.c_char_p, C.POINTER(C.c_float), _I64, C.POINTER(_I64)]),
+    "s3enc_comm_version": (C.c_int, [C.POINTER(_I32)]),
+    "s3enc_comm_unique_id": (C.c_int, [_VP]),
+    "s3enc_comm_init_rank": (C.c_int, [_VP, _I32, _I32, _I32, C.POINTER(_VP)]),
+    "s3enc_comm_info": (C.c_int, [_VP, C.POINTER(_I32), C.POINTER(_I32)]),
+    "s3enc_comm_allgather_states": (C.c_int, [_VP, _VP, _I64, _VP, _I64, _I32, _I64, C.POINTER(_VP), _VP]),
+    "s3enc_comm_destroy": (C.c_int, [_VP]),
+    "s3enc_set_handle_tuning": (C.c_int, [_VP, C.c_char_p, _I32]),
     "s3enc_set_tuning": (C.c_int, [C.c_char_p, _I32]),
     "s3enc_op_gemm": (C.c_int, [_I32, _VP, _I64, _I64, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _VP, _VP, _VP, _VP,
                                 _I64, _I64, _VP]),

@@ -694,7 +694,6 @@ __global__ __launch_bounds__(256) void wavlm_gate_kernel(const float* x, const f
 
 }  // namespace
 
-int g_attn_lds_pad = 0;  // tuning: extra dynamic LDS per workgroup of the 16-bit kernel (caps the workgroups per CU)
 
 hipError_t launch_attention(int dtype, const AttnParams& p, hipStream_t s) {
     if (p.B <= 0 || p.T <= 0) return hipSuccess;
@@ -707,11 +706,11 @@ hipError_t launch_attention(int dtype, const AttnParams& p, hipStream_t s) {
         case F32: hipLaunchKernelGGL(attn_f32_kernel, grid, block, dyn, s, p); break;
         case BF16:
             if (p.bias_table) hipLaunchKernelGGL((attn_h16_kernel<bf16_tag, true>), grid, block, dyn, s, p);
-            else hipLaunchKernelGGL((attn_h16_kernel<bf16_tag, false>), grid, block, dyn + g_attn_lds_pad, s, p);
+            else hipLaunchKernelGGL((attn_h16_kernel<bf16_tag, false>), grid, block, dyn + tuning().attn_lds_pad, s, p);
             break;
         case F16:
             if (p.bias_table) hipLaunchKernelGGL((attn_h16_kernel<f16_tag, true>), grid, block, dyn, s, p);
-            else hipLaunchKernelGGL((attn_h16_kernel<f16_tag, false>), grid, block, dyn + g_attn_lds_pad, s, p);
+            else hipLaunchKernelGGL((attn_h16_kernel<f16_tag, false>), grid, block, dyn + tuning().attn_lds_pad, s, p);
             break;
         case 3: {  // S3ENC_F32X3: fp32 q|k|v and output, split-precision products; all of its LDS is dynamic
             const size_t lds = (size_t)(4 * KBUF16 + 4 * VBUF16) * sizeof(u16) + dyn;

@@ -1,0 +1,179 @@
+// comm.hip — the data-parallel exchange of the path behind the C ABI (include/s3enc.h "multi-GPU"):
+// one process (or thread) per GPU, utterances sharded in contiguous blocks, every rank's (states, shard, T, D) slab
+// re-assembled into (states, world * shard, T, D) with ONE RCCL all-gather per state, so that hidden_states[l] comes out as a
+// contiguous (B, T, D) block in rank order (a single flat gather would be rank-major across states).  The gather of state l
+// is ordered after the event the encoder records when that state is final (s3enc_set_layer_events) and runs on the
+// communicator's own stream: all but the last gather overlap the remaining layers' compute.
+//
+// RCCL is reached through dlopen("librccl.so.1"): a process that already loaded a copy (PyTorch ships one) keeps using that
+// one, a plain C / Go / Rust binder gets /opt/rocm/lib's, and libs3enc.so has no link-time dependency on it.  xGMI is
+// point-to-point (7 links per GPU): RCCL picks the ring / direct algorithm; nothing here assumes a switch.
+#include <dlfcn.h>
+
+#include "engine_internal.h"
+
+namespace {
+
+typedef int ncclResult_t;
+typedef struct ncclComm* ncclComm_t;
+struct ncclUniqueId {
+    char internal[128];
+};
+enum { ncclInt8 = 0 };  // an all-gather only moves bytes
+
+struct Rccl {
+    void* lib = nullptr;
+    ncclResult_t (*GetVersion)(int*) = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string why;
+};
+
+Rccl& rccl() {
+    static Rccl r;
+    static bool tried = false;
+    if (tried) return r;
+    tried = true;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) {
+        r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (r.lib) break;
+    }
+    if (!r.lib) {
+        r.why = std::string("librccl.so.1 not found: ") + (dlerror() ? dlerror() : "");
+        return r;
+    }
+    auto sym = [&](const char* s) {
+        void* p = dlsym(r.lib, s);
+        if (!p && r.why.empty()) r.why = std::string("librccl has no symbol ") + s;
+        return p;
+    };
+    r.GetVersion = (decltype(r.GetVersion))sym("ncclGetVersion");
+    r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
+    r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
+    r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+    r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
+    r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
+    r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
+    r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+    return r;
+}
+
+}  // namespace
+
+struct s3enc_comm_s {
+    ncclComm_t comm = nullptr;
+    int world = 1, rank = 0, device = 0;
+    hipStream_t stream = nullptr;  // the communicator's own stream: gathers overlap the encoder's stream
+    hipEvent_t done = nullptr;     // recorded after the last gather of a call; the caller's stream waits for it
+};
+
+#define RCCL_TRY(expr)                                                                                       \
+    do {                                                                                                     \
+        ncclResult_t _r = (expr);                                                                            \
+        if (_r != 0) {                                                                                       \
+            char _b[512];                                                                                    \
+            snprintf(_b, sizeof(_b), "%s failed: %s (%s:%d)", #expr, R.GetErrorString ? R.GetErrorString(_r) : "?", \
+                     __FILE__, __LINE__);                                                                    \
+            return fail(_b);                                                                                 \
+        }                                                                                                    \
+    } while (0)
+
+extern "C" {
+
+int s3enc_comm_version(int32_t* version) {
+    Rccl& R = rccl();
+    if (!R.lib || !R.why.empty()) return fail("s3enc_comm: " + R.why);
+    if (!version) return fail("s3enc_comm_version: null argument");
+    int v = 0;
+    RCCL_TRY(R.GetVersion(&v));
+    *version = v;
+    return 0;
+}
+
+int s3enc_comm_unique_id(void* id128) {
+    Rccl& R = rccl();
+    if (!R.lib || !R.why.empty()) return fail("s3enc_comm: " + R.why);
+    if (!id128) return fail("s3enc_comm_unique_id: null argument");
+    ncclUniqueId id;
+    RCCL_TRY(R.GetUniqueId(&id));
+    memcpy(id128, id.internal, sizeof(id.internal));
+    return 0;
+}
+
+int s3enc_comm_init_rank(const void* id128, int32_t world, int32_t rank, int32_t device, s3enc_comm* out) {
+    Rccl& R = rccl();
+    if (!R.lib || !R.why.empty()) return fail("s3enc_comm: " + R.why);
+    if (!id128 || !out || world < 1 || rank < 0 || rank >= world) return fail("s3enc_comm_init_rank: bad arguments");
+    DeviceGuard dg(device);
+    if (!dg.ok) return fail("s3enc_comm_init_rank: hipSetDevice failed");
+    s3enc_comm_s* c = new s3enc_comm_s();
+    c->world = world;
+    c->rank = rank;
+    c->device = device;
+    ncclUniqueId id;
+    memcpy(id.internal, id128, sizeof(id.internal));
+    ncclResult_t r = R.CommInitRank(&c->comm, world, id, rank);
+    if (r != 0) {
+        std::string msg = std::string("ncclCommInitRank failed: ") + (R.GetErrorString ? R.GetErrorString(r) : "?");
+        delete c;
+        return fail(msg);
+    }
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->done, hipEventDisableTiming) != hipSuccess) {
+        (void)R.CommDestroy(c->comm);
+        delete c;
+        return fail("s3enc_comm_init_rank: stream / event creation failed");
+    }
+    *out = c;
+    return 0;
+}
+
+int s3enc_comm_destroy(s3enc_comm c) {
+    if (!c) return 0;
+    Rccl& R = rccl();
+    DeviceGuard dg(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    if (c->comm && R.CommDestroy) (void)R.CommDestroy(c->comm);
+    if (c->done) (void)hipEventDestroy(c->done);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return 0;
+}
+
+int s3enc_comm_info(s3enc_comm c, int32_t* world, int32_t* rank) {
+    if (!c || !world || !rank) return fail("s3enc_comm_info: null argument");
+    *world = c->world;
+    *rank = c->rank;
+    return 0;
+}
+
+int s3enc_comm_allgather_states(s3enc_comm c, const void* send, int64_t send_state_stride, void* recv, int64_t recv_state_stride,
+                                int32_t n_states, int64_t bytes_per_state, void* const* ready_events, void* stream) {
+    Rccl& R = rccl();
+    if (!R.lib || !R.why.empty()) return fail("s3enc_comm: " + R.why);
+    if (!c || !send || !recv || n_states < 1 || bytes_per_state < 1) return fail("s3enc_comm_allgather_states: bad arguments");
+    if (recv_state_stride < bytes_per_state * c->world || send_state_stride < bytes_per_state)
+        return fail("s3enc_comm_allgather_states: a state stride is smaller than the block it holds");
+    DeviceGuard dg(c->device);
+    hipStream_t caller = (hipStream_t)stream;
+    if (!ready_events) {  // no per-state events: the gathers simply follow everything enqueued on the caller's stream so far
+        HIP_TRY(hipEventRecord(c->done, caller));
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->done, 0));
+    }
+    for (int l = 0; l < n_states; ++l) {
+        if (ready_events) HIP_TRY(hipStreamWaitEvent(c->stream, (hipEvent_t)ready_events[l], 0));
+        RCCL_TRY(R.AllGather((const char*)send + (size_t)l * send_state_stride, (char*)recv + (size_t)l * recv_state_stride,
+                             (size_t)bytes_per_state, ncclInt8, c->comm, c->stream));
+    }
+    HIP_TRY(hipEventRecord(c->done, c->stream));
+    HIP_TRY(hipStreamWaitEvent(caller, c->done, 0));  // the caller's later work sees the gathered states
+    return 0;
+}
+
+}  // extern "C"

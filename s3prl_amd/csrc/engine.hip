@@ -11,7 +11,6 @@
 namespace s3e {
 
 thread_local std::string g_err;
-int g_x3_pack_cache = 0;
 
 long conv_len(const s3enc_config& c, long n, int upto /*exclusive*/) {
     for (int i = 0; i < upto; ++i) n = n >= c.conv_kernel[i] ? (n - c.conv_kernel[i]) / c.conv_stride[i] + 1 : 0;
@@ -549,6 +548,7 @@ struct Sink {
 int forward_impl(s3enc_handle e, const float* const* wav_ptrs_host, const int64_t* lengths, int32_t B, int64_t n_max_in,
                  const FwdOpts& fo, void* out, int64_t layer_stride, hipStream_t st) {
     const s3enc_config& c = e->cfg;
+    TuningScope tuning_scope(e->has_tuning ? &e->tun : nullptr);
     const int C = c.conv_dim, D = c.embed_dim, F = c.ffn_dim, H = c.heads, NL = c.encoder_layers;
     const int dt = e->dtype, es = e->es;
     const bool dist = c.family == S3ENC_DISTILLER;

@@ -22,7 +22,6 @@ using namespace s3;
 
 
 extern thread_local std::string g_err;  // s3enc_last_error()
-extern int g_x3_pack_cache;
 
 inline int fail(const std::string& msg) {
     g_err = msg;
@@ -252,6 +251,9 @@ struct s3enc_encoder {
     std::vector<BlockW> mr_blocks;      // S3ENC_MULTIRES: encoders..., middle_encoder, decoders... (execution order)
     std::vector<AdapterW> mr_adapters;  // downsample_modules[0..R-2], then upsample_modules[0..R-2]
     DevBuf ws_mr;                       // activation workspace of the U-net behind post_extract_proj
+
+    Tuning tun;               // s3enc_set_handle_tuning: this handle's own kernel-variant selection ...
+    bool has_tuning = false;  // ... in force (for the calling thread) while its forward enqueues kernels
 
     DevBuf ws;      // activation workspace
     DevBuf small;   // tables, stats

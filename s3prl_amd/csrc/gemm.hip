@@ -288,15 +288,14 @@ __global__ __launch_bounds__(256, ROWB == 128 ? 2 : (GLDS ? 5 : 3)) void gemm_ke
 }
 
 }  // namespace
-int g_gemm_lds_pad = 0;
 namespace {
 
 template <typename T, int ROWB, bool GLDS, bool VEC>
 hipError_t gemm_go(const GemmParams& p, dim3 grid, hipStream_t stream) {
     constexpr int lds0 = 2 * (BM + BN) * ROWB;
     static_assert(lds0 >= 4 * 8192, "epilogue staging must fit");
-    // g_gemm_lds_pad (tuning key "gemm_lds_pad", occupancy probe): unused extra LDS so that fewer workgroups fit a CU
-    const int lds = lds0 + g_gemm_lds_pad;
+    // tuning key "gemm_lds_pad" (occupancy probe): unused extra LDS so that fewer workgroups fit a CU
+    const int lds = lds0 + tuning().gemm_lds_pad;
     hipError_t e = ensure_dynamic_lds<gemm_kernel<T, ROWB, GLDS, VEC>>(lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((gemm_kernel<T, ROWB, GLDS, VEC>), grid, dim3(256), lds, stream, p);
@@ -320,11 +319,10 @@ hipError_t gemm_variant(const GemmParams& p, dim3 grid, hipStream_t stream, bool
 
 }  // namespace
 
-int g_gemm_variant = 3;  // 64-byte stages + LDS-DMA (falls back to register staging for a ragged K)
 
 hipError_t launch_gemm(int dtype, const GemmParams& p0, hipStream_t stream) {
     GemmParams p = p0;
-    if (p.variant < 0) p.variant = g_gemm_variant;
+    if (p.variant < 0) p.variant = tuning().gemm_variant;  // default 3: 64-byte stages + LDS-DMA (register staging for a ragged K)
     if (p.M <= 0 || p.N <= 0 || p.batches <= 0) return hipSuccess;
     if (dtype == F32 && gemm_x3_eligible(p)) {
         if (gemm_tile_eligible(3, p)) return launch_gemm_tile(3, p, stream);

@@ -241,7 +241,8 @@ __global__ __launch_bounds__(128 * WN, WPE) void gemm16_big_kernel(GemmParams p)
         if constexpr (SPEC && decltype(o16_c)::value && !decltype(o32_c)::value && !decltype(res_c)::value) {
             // 16-bit output only (conv1-5, q|k|v, fc1): 8 lanes x 8 columns per row, ONE 16-byte store per lane and pass
             // (8-byte stores are issue-bound at 2.1-2.8 TB/s on this chip, 16-byte ones reach 5 TB/s: profiles/r02_gemm16_variants.md)
-            if (!(p.N & 7)) {
+            // (16-byte stores: every row start of the 16-bit output must be 16-byte aligned, not just 8)
+            if (!(p.N & 7) && !(p.ldo & 7) && !(p.o_bs & 7) && !((uintptr_t)p.out16 & 15)) {
                 const int c8 = (lane & 7) * 8;
                 const int n8 = n0 + wc * 64 + c8;
                 const bool n8_ok = n8 < p.N;
@@ -361,10 +362,8 @@ hipError_t big_mode(int mode, const GemmParams& p, hipStream_t stream) {
 
 }  // namespace
 
-int g_gemm16_big = 3;  // 0 off, 3 = choose by shape, 1 / 2 / 4 / 5 / 6 = force one configuration (see big_mode)
-
 bool gemm16_big_eligible(int dtype, const GemmParams& p) {
-    if (dtype == F32 || g_gemm16_big == 0) return false;
+    if (dtype == F32 || tuning().gemm16_big == 0) return false;
     if ((p.K & 63) || (p.N & 3) || (p.ldo & 3) || (p.o_bs & 3)) return false;
     if (((p.lda * 2) & 15) || ((p.a_bs * 2) & 15)) return false;
     const uintptr_t al = (uintptr_t)p.A | (uintptr_t)p.W | (uintptr_t)p.out32 | (uintptr_t)p.residual | (uintptr_t)p.bias;
@@ -374,7 +373,7 @@ bool gemm16_big_eligible(int dtype, const GemmParams& p) {
 }
 
 hipError_t launch_gemm16_big(int dtype, const GemmParams& p, hipStream_t stream) {
-    int mode = g_gemm16_big;
+    int mode = tuning().gemm16_big;  // 0 off, 3 = choose by shape, 1 / 2 / 4 / 5 / 6 = force one configuration (see big_mode)
     if (mode == 3) {
         // measured on MI355X (tools/gemm_bench.py, profiles/r02_gemm16_variants.md, and in the full forward with
         // `bench.py --tune gemm16_big=1|4`): with 16-byte stores in the 16-bit epilogues the one-workgroup-per-CU 256x256 /

@@ -334,9 +334,6 @@ double tile_efficiency(const GemmParams& p, int tm, int cus) {
 
 }  // namespace
 
-int g_gemm32_big = 1;    // fp32: 0 off, 1 = tile height by shape (default), 2 / 3 / 4 / 5 = force 256 / 192 / 128 / 64 rows (measurement)
-int g_gemm_x3_tile = 1;  // S3ENC_F32X3: 0 off, 1 = only where it beats gemm_x3.hip's lock-step 256x256 tile (default), 2..5 = force a height
-
 namespace {
 int device_cus() {
     static int cus = 0;
@@ -377,7 +374,7 @@ int gemm_tile_pick(int mode, const GemmParams& p) {
 // MFMA rate a 128-byte LDS fragment read per 32 cycles of MFMA is what bounds a 64-column wave tile.
 bool gemm_tile_eligible(int dtype, const GemmParams& p) {
     if (dtype != F32 && dtype != 3) return false;
-    const int mode = dtype == F32 ? g_gemm32_big : g_gemm_x3_tile;
+    const int mode = dtype == F32 ? tuning().gemm32_big : tuning().gemm_x3_tile;
     if (!mode || !p.out32 || p.out16) return false;
     if (dtype == 3 && !p.W_x3) return false;
     if ((p.K & 15) || (p.N & 3) || (p.ldo & 3) || (p.o_bs & 3) || ((p.lda * 4) & 15) || ((p.a_bs * 4) & 15)) return false;
@@ -399,7 +396,7 @@ bool gemm_tile_eligible(int dtype, const GemmParams& p) {
 }
 
 hipError_t launch_gemm_tile(int dtype, const GemmParams& p, hipStream_t stream) {
-    const int tm = gemm_tile_pick(dtype == F32 ? g_gemm32_big : g_gemm_x3_tile, p);
+    const int tm = gemm_tile_pick(dtype == F32 ? tuning().gemm32_big : tuning().gemm_x3_tile, p);
     return dtype == 3 ? go_tm<x3_tag>(tm, p, stream) : go_tm<float>(tm, p, stream);
 }
 

@@ -21,6 +21,29 @@ inline hipError_t ensure_dynamic_lds(int bytes) {
     return e;
 }
 
+// ---- kernel-variant selection (A/B measurement knobs; results never depend on them) -------------------------
+// One struct instead of scattered globals: `g_tuning` holds the process defaults (s3enc_set_tuning); a handle may carry its
+// own copy (s3enc_set_handle_tuning), which the engine makes current for the calling thread while that handle's forward
+// enqueues its kernels (TuningScope) — so two handles, or two threads, never see each other's settings.
+struct Tuning {
+    int gemm_variant = 3;  // gemm.hip: bit 0 = 64-byte K stages, bit 1 = LDS-DMA staging, bit 2 = no XCD-aware tile order
+    int gemm_lds_pad = 0;  // gemm.hip occupancy probe: extra (unused) dynamic LDS per workgroup
+    int gemm32_big = 1;    // gemmt.hip, fp32: 0 off, 1 = tile height by shape, 2..5 = force 256 / 192 / 128 / 64 rows
+    int gemm_x3_tile = 1;  // gemmt.hip, S3ENC_F32X3: 0 off, 1 = only the shapes with few tiles, 2..5 = force a height
+    int gemm16_big = 3;    // gemm16.hip: 0 off, 3 = choose by shape, 1 / 2 / 4 / 5 / 6 = force one configuration
+    int attn_lds_pad = 0;  // 16-bit attention occupancy probe
+    int x3_pack_cache = 0; // s3enc_op_gemm(S3ENC_F32X3): keep the packed image of the last weight (micro-benchmarks)
+};
+extern Tuning g_tuning;
+extern thread_local const Tuning* t_tuning;  // the current handle's override, or null
+inline const Tuning& tuning() { return t_tuning ? *t_tuning : g_tuning; }
+struct TuningScope {
+    const Tuning* prev;
+    explicit TuningScope(const Tuning* t) : prev(t_tuning) { if (t) t_tuning = t; }
+    ~TuningScope() { t_tuning = prev; }
+};
+int tuning_set(Tuning& t, const char* key, int value, const char** err);  // 0 ok; ops.hip
+
 // ---- gemm.hip -----------------------------------------------------------------------------------------
 struct GemmParams {
     const void* A;  // (batches, M, K) rows at A + b*a_bs + m*lda (elements of the compute dtype)
@@ -35,22 +58,18 @@ struct GemmParams {
     float* out32;
     void* out16;
     long ldo, o_bs;
-    int variant = -1;  // tuning knob: -1 = library default (g_gemm_variant)
+    int variant = -1;  // tuning knob: -1 = the current tuning().gemm_variant
 };
-extern int g_gemm_variant;
-extern int g_gemm_lds_pad;  // occupancy probe: extra (unused) dynamic LDS per workgroup of gemm_kernel
 // gemm_x3.hip: fp32-class GEMM from three bf16 MFMAs per product (opt-in compute mode S3ENC_F32X3)
 bool gemm_x3_eligible(const GemmParams& p);
 hipError_t launch_gemm_x3(const GemmParams& p, hipStream_t stream);
 void pack_x3(const float* w, long N, long K, std::vector<uint16_t>& out);  // host: fp32 (N, K) -> pair-packed bf16 hi / lo
-// gemm16.hip: large-tile LDS-DMA kernel for the 16-bit modes (0 off, 1 = 256x256, 2 = 128x256, 3 = by tile count)
-extern int g_gemm16_big;
+// gemm16.hip: large-tile LDS-DMA kernel for the 16-bit modes (tuning().gemm16_big)
 bool gemm16_big_eligible(int dtype, const GemmParams& p);
 hipError_t launch_gemm16_big(int dtype, const GemmParams& p, hipStream_t stream);
 // gemmt.hip: (256 | 192 | 128 | 64) x 128 tiles, several independent workgroups per CU; fp32 results bit-identical to
-// gemm.hip's kernel.  Tuning keys: 0 off, 1 = tile height by shape, 2..5 = force 256 / 192 / 128 / 64 rows
-extern int g_gemm32_big;   // fp32 mode (default 1)
-extern int g_gemm_x3_tile; // S3ENC_F32X3 (dtype code 3 below: fp32 operands, the pair-packed p.W_x3)
+// gemm.hip's kernel.  tuning().gemm32_big (fp32) / .gemm_x3_tile (S3ENC_F32X3 = dtype code 3 below: fp32 operands, the
+// pair-packed p.W_x3)
 bool gemm_tile_eligible(int dtype, const GemmParams& p);
 hipError_t launch_gemm_tile(int dtype, const GemmParams& p, hipStream_t stream);
 hipError_t launch_gemm(int dtype, const GemmParams& p, hipStream_t stream);
@@ -125,7 +144,6 @@ struct AttnParams {
     const float* gate;        // WavLM: [B][H][T] or null (then gate = 1)
     int probe = 0;            // timing probes (tools/micro/attn_lab.hip builds the kernels with S3_ATTN_PROBE; ignored otherwise)
 };
-extern int g_attn_lds_pad;
 hipError_t launch_attention(int dtype, const AttnParams& p, hipStream_t s);
 // WavLM gate (wavlm/modules.py:535-549) from the layer input x (fp32 rows of D): gate[b][h][t]
 hipError_t launch_wavlm_gate(const float* x, const float* grep_w /*[8][64]*/, const float* grep_b /*[8]*/,

@@ -2,45 +2,59 @@
 // op-level tests and micro-benchmarks call (s3enc_op_*), the Featurizer's weighted sum and the fbank upstream.
 #include "engine_internal.h"
 
+namespace s3 {
+Tuning g_tuning;
+thread_local const Tuning* t_tuning = nullptr;
+
+int tuning_set(Tuning& t, const char* key, int value, const char** err) {
+    struct Key {
+        const char* name;
+        int Tuning::*field;
+        int lo, hi;
+    };
+    static const Key keys[] = {
+        {"gemm_variant", &Tuning::gemm_variant, 0, 63},      {"gemm_lds_pad", &Tuning::gemm_lds_pad, 0, 120 * 1024},
+        {"gemm32_big", &Tuning::gemm32_big, 0, 5},           {"gemm_x3_tile", &Tuning::gemm_x3_tile, 0, 5},
+        {"gemm16_big", &Tuning::gemm16_big, 0, 6},           {"attn_lds_pad", &Tuning::attn_lds_pad, 0, 48 * 1024},
+        {"x3_pack_cache", &Tuning::x3_pack_cache, 0, 1},
+    };
+    static thread_local char msg[160];
+    if (!key) {
+        *err = "s3enc_set_tuning: null key";
+        return 1;
+    }
+    for (const Key& k : keys)
+        if (!strcmp(key, k.name)) {
+            if (value < k.lo || value > k.hi) {
+                snprintf(msg, sizeof(msg), "%s must be %d..%d", k.name, k.lo, k.hi);
+                *err = msg;
+                return 1;
+            }
+            t.*(k.field) = value;
+            return 0;
+        }
+    snprintf(msg, sizeof(msg), "s3enc_set_tuning: unknown key '%s'", key);
+    *err = msg;
+    return 1;
+}
+}  // namespace s3
+
 extern "C" {
 
 int s3enc_set_tuning(const char* key, int32_t value) {
-    if (!key) return fail("s3enc_set_tuning: null key");
-    if (!strcmp(key, "gemm_variant")) {
-        if (value < 0 || value > 63) return fail("gemm_variant must be 0..63");
-        g_gemm_variant = value;
-        return 0;
+    const char* err = nullptr;
+    if (tuning_set(g_tuning, key, value, &err)) return fail(err);
+    return 0;
+}
+int s3enc_set_handle_tuning(s3enc_handle h, const char* key, int32_t value) {
+    if (!h) return fail("null handle");
+    if (!h->has_tuning) {
+        h->tun = g_tuning;  // start from the process defaults as they are now
+        h->has_tuning = true;
     }
-    if (!strcmp(key, "gemm32_big")) {
-        if (value < 0 || value > 5) return fail("gemm32_big must be 0..5");
-        g_gemm32_big = value;
-        return 0;
-    }
-    if (!strcmp(key, "gemm_x3_tile")) {
-        if (value < 0 || value > 5) return fail("gemm_x3_tile must be 0..5");
-        g_gemm_x3_tile = value;
-        return 0;
-    }
-    if (!strcmp(key, "gemm_lds_pad")) {
-        if (value < 0 || value > 120 * 1024) return fail("gemm_lds_pad must be 0..122880");
-        g_gemm_lds_pad = value;
-        return 0;
-    }
-    if (!strcmp(key, "gemm16_big")) {
-        if (value < 0 || value > 6) return fail("gemm16_big must be 0..6");
-        g_gemm16_big = value;
-        return 0;
-    }
-    if (!strcmp(key, "attn_lds_pad")) {
-        if (value < 0 || value > 48 * 1024) return fail("attn_lds_pad must be 0..49152");
-        g_attn_lds_pad = value;
-        return 0;
-    }
-    if (!strcmp(key, "x3_pack_cache")) {
-        g_x3_pack_cache = value != 0;
-        return 0;
-    }
-    return fail(std::string("s3enc_set_tuning: unknown key '") + key + "'");
+    const char* err = nullptr;
+    if (tuning_set(h->tun, key, value, &err)) return fail(err);
+    return 0;
 }
 
 // ---- single-kernel entry points -------------------------------------------------------------------------------
@@ -71,7 +85,7 @@ int s3enc_op_gemm(int32_t dtype, const void* A, int64_t lda, int64_t a_batch_str
         static DevBuf cached;
         static const void* cached_w = nullptr;
         static long cached_n = 0, cached_k = 0;
-        if (g_x3_pack_cache && cached_w == W && cached_n == N && cached_k == K) {
+        if (tuning().x3_pack_cache && cached_w == W && cached_n == N && cached_k == K) {
             g.W_x3 = cached.p;
             if (!gemm_x3_eligible(g)) return fail("s3enc_op_gemm: shape / alignment not eligible for the S3ENC_F32X3 kernel");
             HIP_TRY(launch_gemm(F32, g, (hipStream_t)stream));
@@ -85,7 +99,7 @@ int s3enc_op_gemm(int32_t dtype, const void* A, int64_t lda, int64_t a_batch_str
         if (!gemm_x3_eligible(g)) return fail("s3enc_op_gemm: shape / alignment not eligible for the S3ENC_F32X3 kernel");
         HIP_TRY(launch_gemm(F32, g, (hipStream_t)stream));
         HIP_TRY(hipStreamSynchronize((hipStream_t)stream));  // w3 is freed on return (or kept as the cache)
-        if (g_x3_pack_cache) {
+        if (tuning().x3_pack_cache) {
             HIP_TRY(hipDeviceSynchronize());
             std::swap(cached.p, w3.p);
             std::swap(cached.bytes, w3.bytes);

@@ -124,6 +124,65 @@ def gather_layers(hs: torch.Tensor, group=None, overlap_events: Optional[list] =
     return result
 
 
+class RcclComm:
+    """The library's own exchange (``s3enc_comm_*`` in include/s3enc.h: RCCL reached from ``libs3enc.so``, one all-gather
+    per state on the communicator's stream, each ordered after the encoder's "state l final" event) — the path a non-Python
+    binder uses, behind the same call shape as ``gather_layers``.  The 128-byte RCCL id travels over ``torch.distributed``
+    when a process group exists (any backend), else ``world`` must be 1."""
+
+    def __init__(self, device: Optional[int] = None, group=None):
+        import ctypes as C
+
+        import torch.distributed as dist
+
+        from . import _lib
+
+        self._lib, self._C = _lib.load(), C
+        self.device = torch.cuda.current_device() if device is None else int(device)
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        ident = C.create_string_buffer(128)
+        if rank == 0:
+            _lib.check(self._lib.s3enc_comm_unique_id(ident), "s3enc_comm_unique_id")
+        if world > 1:
+            box = [bytes(ident.raw)]
+            dist.broadcast_object_list(box, src=0, group=group)
+            ident = C.create_string_buffer(box[0], 128)
+        h = C.c_void_p()
+        _lib.check(self._lib.s3enc_comm_init_rank(ident, world, rank, self.device, C.byref(h)), "s3enc_comm_init_rank")
+        self._h, self.world, self.rank = h, world, rank
+
+    def gather_layers(self, hs: torch.Tensor, overlap_events: Optional[list] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """(NS, Bs, T, D) on this rank -> (NS, world * Bs, T, D); asynchronous on the current stream."""
+        C = self._C
+        from . import _lib
+
+        NS = hs.shape[0]
+        per_state = hs[0].numel() * hs.element_size()
+        assert hs.is_cuda and hs[0].is_contiguous() and hs.stride(0) * hs.element_size() >= per_state
+        if out is None:
+            out = torch.empty((NS, self.world * hs.shape[1]) + tuple(hs.shape[2:]), dtype=hs.dtype, device=hs.device)
+        evs = None
+        if overlap_events is not None:
+            evs = (C.c_void_p * NS)(*[int(ev.cuda_event) for ev in overlap_events[:NS]])
+        stream = torch.cuda.current_stream(hs.device).cuda_stream
+        _lib.check(self._lib.s3enc_comm_allgather_states(self._h, C.c_void_p(hs.data_ptr()), hs.stride(0) * hs.element_size(),
+                                                         C.c_void_p(out.data_ptr()), out.stride(0) * out.element_size(), NS,
+                                                         per_state, evs, C.c_void_p(stream)), "s3enc_comm_allgather_states")
+        return out
+
+    def close(self):
+        if self._h:
+            self._lib.s3enc_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class DataParallelUpstream(torch.nn.Module):
     """Wraps a ``HipUpstreamExpert``: same ``forward(wavs) -> dict`` contract, batch sharded over the process group."""
 

@@ -140,3 +140,34 @@ def test_two_ranks_featurized_and_16bit_exchange():
     assert np.array_equal(by["hs16"][0], by["hs16"][1])
     assert abs(by["sum"][0] - float(np.abs(by["feat"][0].astype(np.float64)).sum())) < 1e-6 * by["sum"][0]
     assert abs(by["sum"][1] - float(np.abs(by["hs16"][0].astype(np.float64)).sum())) < 1e-6 * by["sum"][1]
+
+
+def test_cabi_rccl_exchange_world_1():
+    """The exchange behind the C ABI (s3enc_comm_*: RCCL dlopen'ed by libs3enc.so) on a one-rank communicator — the only
+    world size this box's single GPU allows RCCL (it refuses two ranks on one device): per-state all-gathers on the
+    communicator's stream, each behind the encoder's "state l final" event, reproduce the slab bit for bit, for a strided
+    receive buffer too; the same entry points serve N ranks."""
+    import torch
+
+    from s3prl_amd.parallel import RcclComm
+    from s3prl_amd.synth import named_config, synth_wavs, synth_weights
+    from s3prl_amd.upstream.hubert.expert import UpstreamExpert
+
+    cfg = named_config("tiny_hubert")
+    expert = UpstreamExpert.from_weights(cfg, synth_weights(cfg, 2))
+    wavs = [torch.from_numpy(w).cuda() for w in synth_wavs([4000, 3111, 2345], 9)]
+    comm = RcclComm()
+    assert (comm.world, comm.rank) == (1, 0)
+    enc = expert._encoder_for(wavs[0].device)
+    events = enc.layer_events()
+    hs = expert.encode(wavs)  # (NS, B, T, D); the events were recorded as each state became final
+    out = comm.gather_layers(hs, overlap_events=events)
+    torch.cuda.synchronize()
+    assert torch.equal(out, hs)
+    # a receive slab whose state stride is wider than one rank's block (what an N-rank gather writes into)
+    flat = torch.full((hs.shape[0], 3 * hs[0].numel()), float("nan"), device="cuda")
+    view = flat.as_strided(hs.shape, (flat.stride(0),) + tuple(hs[0].stride()))
+    comm.gather_layers(hs, out=view)
+    torch.cuda.synchronize()
+    assert torch.equal(view, hs) and torch.isnan(flat[:, hs[0].numel():]).all()
+    comm.close()
