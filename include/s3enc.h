@@ -48,7 +48,13 @@ enum { S3ENC_F32 = 0, S3ENC_BF16 = 1, S3ENC_F16 = 2,
        /* fp32 data flow (activations, norms, softmax, attention, positional conv exactly as S3ENC_F32) with the GEMMs
         * computed as three bf16 MFMAs per product on split operands (x = hi + lo): ~1e-5 relative error per GEMM at
         * 3/16 of the exact-fp32 matrix cost.  Opt-in; S3ENC_F32 stays the exact default. */
-       S3ENC_F32X3 = 3 };
+       S3ENC_F32X3 = 3,
+       /* fp16 data flow (exactly S3ENC_F16: fp16 activations / attention, fp32 accumulate, norms, softmax, residual) with
+        * every GEMM weight kept as TWO fp16 terms (w = hi + lo) and the contraction run over both: the weights' rounding
+        * error disappears, leaving the activations' — 0.65-0.70e-3 relative error on the hidden states instead of
+        * S3ENC_F16's 0.9-1.3e-3, i.e. inside the path's 1e-3 tolerance at 16-bit bandwidth and 2/16 of the exact matrix cost
+        * (S3ENC_F32X3: 3/16, 1e-5).  Opt-in. */
+       S3ENC_F16X2 = 4 };
 
 /* Hyper-parameters that select kernel variants.
  * Replaces: HubertConfig / HubertPretrainingConfig (upstream/hubert/hubert_model.py:33-278),
@@ -74,7 +80,7 @@ typedef struct s3enc_config {
     int32_t num_buckets;
     int32_t max_distance;
     int32_t gru_rel_pos;
-    int32_t compute_dtype;                 /* S3ENC_F32 / BF16 / F16 / F32X3 */
+    int32_t compute_dtype;                 /* S3ENC_F32 / BF16 / F16 / F32X3 / F16X2 */
     int32_t no_feature_layer_norm;         /* 1: post_extract_proj reads the conv output directly (distiller/model.py:170-176) */
     int32_t pos_conv_depth;                /* data2vec: > 1 = that many {Conv1d(D, D, max(3, conv_pos / depth), groups) -> LayerNorm(no
                                             * affine) -> GELU} blocks instead of the single weight-normed conv (wav2vec2_model.py:2995-3023);
@@ -232,7 +238,8 @@ int s3enc_set_handle_tuning(s3enc_handle h, const char* key, int32_t value);
  * (elements; lda < K expresses an overlapping strided-conv window), W is (N, K) row-major.
  * epilogue: + bias[n]; GELU if act; + residual (fp32, same indexing as out32); rows m >= row_limit[b] -> 0.
  * Writes out32 (fp32) and/or out16 (dtype) when non-NULL.  dtype S3ENC_F32X3: fp32 A / W / out32, three bf16 MFMAs per
- * product (K % 32 == 0, M, N >= 128; synchronises). */
+ * product (K % 32 == 0, M, N >= 128; synchronises).  dtype S3ENC_F16X2: fp16 A and out16, W is the (N, 2K) fp16 image
+ * [hi(K) | lo(K)] per row with w = hi + lo (K % 64 == 0, else only the hi half is used). */
 int s3enc_op_gemm(int32_t dtype, const void* A, int64_t lda, int64_t a_batch_stride, const void* W,
                   const float* bias, int32_t M, int32_t N, int32_t K, int32_t batches, int32_t act,
                   const float* residual, const int32_t* row_limit, float* out32, void* out16, int64_t ldo,

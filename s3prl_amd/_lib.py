@@ -14,9 +14,10 @@ LIB_PATH = os.path.join(_HERE, "libs3enc.so")
 
 S3ENC_MAX_CONV = 16
 S3ENC_MAX_RES = 4
-F32, BF16, F16, F32X3 = 0, 1, 2, 3
+F32, BF16, F16, F32X3, F16X2 = 0, 1, 2, 3, 4
 DTYPES = {"fp32": F32, "f32": F32, "float32": F32, "bf16": BF16, "bfloat16": BF16, "fp16": F16, "f16": F16,
-          "float16": F16, "fp32x3": F32X3, "f32x3": F32X3, "bf16x3": F32X3}
+          "float16": F16, "fp32x3": F32X3, "f32x3": F32X3, "bf16x3": F32X3,
+          "fp16x2": F16X2, "f16x2": F16X2}
 FAMILY = {"hubert": 0, "wav2vec2": 1, "wavlm": 2, "distiller": 3, "multires_hubert": 4}
 SEL_HIDDEN, SEL_LAYER_OUT, SEL_FFN_OUT = 0, 1, 2
 SELECTIONS = {None: SEL_HIDDEN, "hidden_states": SEL_HIDDEN, "fairseq_layers": SEL_LAYER_OUT,

@@ -121,7 +121,7 @@ int check_config(const s3enc_config& c) {
     const int dg = c.embed_dim / c.conv_pos_groups;
     if (dg != 32 && dg != 48 && dg != 64) return fail("config: embed_dim/conv_pos_groups must be 32, 48 or 64");
     if (c.conv_pos < 1 || c.conv_pos > 256) return fail("config: conv_pos out of range");
-    if (c.compute_dtype < 0 || c.compute_dtype > 3) return fail("config: unknown compute_dtype");
+    if (c.compute_dtype < 0 || c.compute_dtype > 4) return fail("config: unknown compute_dtype");
     if (c.encoder_layers < 1) return fail("config: encoder_layers < 1");
     if (c.rel_pos && c.family != S3ENC_WAVLM) return fail("config: rel_pos is a WavLM feature");
     if (c.rel_pos && (c.num_buckets < 4 || c.max_distance <= c.num_buckets / 4))
@@ -162,7 +162,8 @@ int s3enc_create(const s3enc_config* cfg, const s3enc_tensor* tensors, int32_t n
     e->cfg = *cfg;
     e->device = device;
     e->x3 = cfg->compute_dtype == 3;  // S3ENC_F32X3: the fp32 data flow, GEMMs through gemm_x3.hip
-    e->dtype = e->x3 ? (int)F32 : cfg->compute_dtype;
+    e->x2 = cfg->compute_dtype == 4;  // S3ENC_F16X2: the fp16 data flow, GEMM weights split into two fp16 terms
+    e->dtype = e->x3 ? (int)F32 : (e->x2 ? (int)F16 : cfg->compute_dtype);
     e->es = e->dtype == F32 ? 4 : 2;
     const s3enc_config& c = e->cfg;
     const int C = c.conv_dim, D = c.embed_dim, F = c.ffn_dim, H = c.heads;
@@ -198,7 +199,7 @@ int s3enc_create(const s3enc_config* cfg, const s3enc_tensor* tensors, int32_t n
             for (int co = 0; co < C; ++co)
                 for (int ci = 0; ci < cin; ++ci)
                     for (int j = 0; j < k; ++j) t2[((long)co * k + j) * cin + ci] = t[((long)co * cin + ci) * k + j];
-            UP(upload_cvt(e->conv[i].w, t2, e->dtype));
+            UP(upload_gemm_w(e->conv[i].w, t2, C, (long)k * cin, e->dtype, e->x2));
             if (e->x3) UP(upload_x3(e->conv[i].w3, t2, C, (long)k * cin));
         }
         if (c.conv_bias) {
@@ -225,7 +226,7 @@ int s3enc_create(const s3enc_config* cfg, const s3enc_tensor* tensors, int32_t n
         UP(upload_f32(e->fln_b, t));
     }
     GET("post_extract_proj.weight", (long)D * C, t);
-    UP(upload_cvt(e->proj_w, t, e->dtype));
+    UP(upload_gemm_w(e->proj_w, t, D, C, e->dtype, e->x2));
     if (e->x3) UP(upload_x3(e->proj_w3, t, D, C));
     GET("post_extract_proj.bias", D, t);
     UP(upload_f32(e->proj_b, t));
@@ -314,11 +315,11 @@ int s3enc_create(const s3enc_config* cfg, const s3enc_tensor* tensors, int32_t n
             for (long i = 0; i < (long)D * D; ++i) w[(long)s * D * D + i] = t[i] * sc;
             for (int i = 0; i < D; ++i) bb[(long)s * D + i] = t2[i] * sc;
         }
-        UP(upload_cvt(L.wqkv, w, e->dtype));
+        UP(upload_gemm_w(L.wqkv, w, 3L * D, D, e->dtype, e->x2));
         if (e->x3) UP(upload_x3(L.wqkv3, w, 3L * D, D));
         UP(upload_f32(L.bqkv, bb));
         GET(p + ".self_attn.out_proj.weight", (long)D * D, t);
-        UP(upload_cvt(L.wo, t, e->dtype));
+        UP(upload_gemm_w(L.wo, t, D, D, e->dtype, e->x2));
         if (e->x3) UP(upload_x3(L.wo3, t, D, D));
         GET(p + ".self_attn.out_proj.bias", D, t);
         UP(upload_f32(L.bo, t));
@@ -327,12 +328,12 @@ int s3enc_create(const s3enc_config* cfg, const s3enc_tensor* tensors, int32_t n
         GET(p + ".self_attn_layer_norm.bias", D, t);
         UP(upload_f32(L.ln1b, t));
         GET(p + ".fc1.weight", (long)F * D, t);
-        UP(upload_cvt(L.w1, t, e->dtype));
+        UP(upload_gemm_w(L.w1, t, F, D, e->dtype, e->x2));
         if (e->x3) UP(upload_x3(L.w13, t, F, D));
         GET(p + ".fc1.bias", F, t);
         UP(upload_f32(L.b1, t));
         GET(p + ".fc2.weight", (long)D * F, t);
-        UP(upload_cvt(L.w2, t, e->dtype));
+        UP(upload_gemm_w(L.w2, t, D, F, e->dtype, e->x2));
         if (e->x3) UP(upload_x3(L.w23, t, D, F));
         GET(p + ".fc2.bias", D, t);
         UP(upload_f32(L.b2, t));
@@ -401,7 +402,7 @@ int s3enc_create(const s3enc_config* cfg, const s3enc_tensor* tensors, int32_t n
                                 pk[((long)r * D + co) * K + (long)jp * D + ci] = w[((long)ci * D + co) * k + tap];
                     }
             }
-            UP(upload_cvt(cw.w, pk, e->dtype));
+            UP(upload_gemm_w(cw.w, pk, N, K, e->dtype, e->x2));
             if (e->x3) UP(upload_x3(cw.w3, pk, N, K));
             GET(cp + ".2.weight", D, t);
             UP(upload_f32(cw.g, t));
@@ -441,7 +442,7 @@ int s3enc_create(const s3enc_config* cfg, const s3enc_tensor* tensors, int32_t n
         // weight is (N, Din, Dout) (module.py:66-68); each head becomes an (out, in) row-major GEMM operand
         const int NH = c.pred_heads;
         GET("output_layer.0.weight", (long)NH * D * D, t);
-        UP(upload_cvt(e->head_w1, t, e->dtype));
+        UP(upload_gemm_w(e->head_w1, t, (long)NH * D, D, e->dtype, e->x2));
         if (e->x3) UP(upload_x3(e->head_w13, t, (long)NH * D, D));
         GET("output_layer.0.bias", (long)NH * D, t);
         UP(upload_f32(e->head_b1, t));
@@ -450,7 +451,7 @@ int s3enc_create(const s3enc_config* cfg, const s3enc_tensor* tensors, int32_t n
         for (int k = 0; k < NH; ++k)
             for (int i = 0; i < D; ++i)
                 for (int n = 0; n < D; ++n) t2[((long)k * D + n) * D + i] = t[((long)k * D + i) * D + n];
-        UP(upload_cvt(e->head_w2, t2, e->dtype));
+        UP(upload_gemm_w(e->head_w2, t2, (long)NH * D, D, e->dtype, e->x2));
         if (e->x3) UP(upload_x3(e->head_w23, t2, (long)NH * D, D));
         GET("output_layer.2.bias", (long)NH * D, t);
         UP(upload_f32(e->head_b2, t));
@@ -756,13 +757,13 @@ int forward_impl(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
             g.act = 1;
             if (f32out) g.out32 = (float*)dst; else g.out16 = dst;
             Prof pr(e, st, kind, fl, by);
-            HIP_TRY(launch_gemm(dt, g, st));
+            HIP_TRY(launch_gemm(dt, wsplit_of(e, g), st));
         } else {
             g.act = 0;
             g.out32 = (float*)tmp32;
             {
                 Prof pr(e, st, kind, fl, by);
-                HIP_TRY(launch_gemm(dt, g, st));
+                HIP_TRY(launch_gemm(dt, wsplit_of(e, g), st));
             }
             Prof pr(e, st, "layernorm:conv", 0, (double)B * L[i] * C * (4 + (f32out ? 4 : es)));
             HIP_TRY(launch_layernorm(dt, (const float*)tmp32, (const float*)e->conv[i].lng.p, (const float*)e->conv[i].lnb.p,
@@ -801,7 +802,7 @@ int forward_impl(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
         g.o_bs = T * D;
         {
             Prof pr(e, st, "gemm:proj", 2.0 * M * D * C, ((double)M * C + (double)D * C) * es + (double)M * D * 4);
-            HIP_TRY(launch_gemm(dt, g, st));
+            HIP_TRY(launch_gemm(dt, wsplit_of(e, g), st));
         }
         e->taps["proj"] = {xproj, M * D, F32};
         HIP_TRY(sink.emit(si_proj, xproj, false));
@@ -937,7 +938,7 @@ int forward_impl(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
             g.ldo = 3 * D;
             if (dt == F32) g.out32 = (float*)qkv; else g.out16 = qkv;
             Prof pr(e, st, "gemm:qkv", 2.0 * gM * 3 * D * D, (gM * D + 3.0 * D * D + gM * 3 * D) * es);
-            HIP_TRY(launch_gemm(dt, g, st));
+            HIP_TRY(launch_gemm(dt, wsplit_of(e, g), st));
             if (l == 0) e->taps["qkv0"] = {qkv, M * 3 * D, dt};
         }
         {
@@ -970,7 +971,7 @@ int forward_impl(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
             g.residual = x_cur;
             g.out32 = (float*)tmp1;
             Prof pr(e, st, "gemm:out_proj", 2.0 * gM * D * D, (gM * D + (double)D * D) * es + gM * D * 8);
-            HIP_TRY(launch_gemm(dt, g, st));
+            HIP_TRY(launch_gemm(dt, wsplit_of(e, g), st));
         }
         const float* ffn_res;
         const void* ffn_in;
@@ -1002,7 +1003,7 @@ int forward_impl(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
             g.ldo = F;
             if (dt == F32) g.out32 = (float*)hbuf; else g.out16 = hbuf;
             Prof pr(e, st, "gemm:fc1", 2.0 * gM * F * D, (gM * D + (double)F * D + gM * F) * es);
-            HIP_TRY(launch_gemm(dt, g, st));
+            HIP_TRY(launch_gemm(dt, wsplit_of(e, g), st));
         }
         // fc2 + bias + residual.  pre-LN: the result IS the residual stream after the layer (a state for l < NL-1, and
         // for the fairseq_layers / DistilHuBERT selections); post-LN: it feeds final_layer_norm.
@@ -1031,7 +1032,7 @@ int forward_impl(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
                 g.out16 = sink.slot16(l);
                 {
                     Prof pr(e, st, "gemm:fc2", 2.0 * gM * D * F, (gM * F + (double)D * F) * es + gM * D * 4);
-                    HIP_TRY(launch_gemm(dt, g, st));
+                    HIP_TRY(launch_gemm(dt, wsplit_of(e, g), st));
                 }
                 HIP_TRY(sink.emit(l, f_out, false));
                 HIP_TRY(sink.done(l));
@@ -1042,7 +1043,7 @@ int forward_impl(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
                 g.out32 = fc2_dst;
                 g.out16 = prel ? sink.slot16(si_next) : nullptr;
                 Prof pr(e, st, "gemm:fc2", 2.0 * gM * D * F, (gM * F + (double)D * F) * es + gM * D * 8);
-                HIP_TRY(launch_gemm(dt, g, st));
+                HIP_TRY(launch_gemm(dt, wsplit_of(e, g), st));
             }
         }
         if (!prel) {
@@ -1089,7 +1090,7 @@ int forward_impl(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
             g.ldo = (long)NH * D;
             if (dt == F32) g.out32 = (float*)hbuf; else g.out16 = hbuf;
             Prof pr(e, st, "gemm:head1", 2.0 * gM * NH * D * D, (gM * D + (double)NH * D * D + gM * NH * D) * es);
-            HIP_TRY(launch_gemm(dt, g, st));
+            HIP_TRY(launch_gemm(dt, wsplit_of(e, g), st));
         }
         for (int k = 0; k < NH; ++k) {
             const int si = 1 + NL + k;
@@ -1097,7 +1098,7 @@ int forward_impl(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
             GemmParams g{};
             g.A = (const char*)hbuf + (size_t)k * D * es;
             g.lda = (long)NH * D;
-            g.W = (const char*)e->head_w2.p + (size_t)k * D * D * es;
+            g.W = (const char*)e->head_w2.p + (size_t)k * D * D * es * (e->x2 ? 2 : 1);  // x2: rows are [hi | lo]
             g.W_x3 = e->head_w23.p ? (const char*)e->head_w23.p + (size_t)k * D * D * 4 : nullptr;
             g.bias = (const float*)e->head_b2.p + (long)k * D;
             g.M = (int)M;
@@ -1109,7 +1110,7 @@ int forward_impl(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
             g.out16 = sink.slot16(si);
             {
                 Prof pr(e, st, "gemm:head2", 2.0 * gM * D * D, (gM * D + (double)D * D) * es + gM * D * 4);
-                HIP_TRY(launch_gemm(dt, g, st));
+                HIP_TRY(launch_gemm(dt, wsplit_of(e, g), st));
             }
             HIP_TRY(sink.emit(si, dst, false));
             HIP_TRY(sink.done(si));

@@ -165,6 +165,25 @@ inline void pack_posconv(const std::vector<float>& w, int D, int G, int K, int d
                 }
 }
 
+// S3ENC_F16X2: a GEMM weight (N, K) as fp16 rows [hi(K) | lo(K)], w = hi + lo + O(2^-22 |w|)
+inline hipError_t upload_f16_hi_lo(DevBuf& d, const std::vector<float>& v, long N, long K) {
+    std::vector<uint16_t> h((size_t)N * 2 * K);
+    for (long n = 0; n < N; ++n)
+        for (long k = 0; k < K; ++k) {
+            const float w = v[(size_t)n * K + k];
+            const uint16_t hi = h_f16(w);
+            h[(size_t)n * 2 * K + k] = hi;
+            h[(size_t)n * 2 * K + K + k] = h_f16(w - h_from16(hi, F16));
+        }
+    hipError_t e = d.ensure(h.size() * 2 + 16);
+    if (e != hipSuccess) return e;
+    return hipMemcpy(d.p, h.data(), h.size() * 2, hipMemcpyHostToDevice);
+}
+// a GEMM operand weight (N, K) in the handle's operand format
+inline hipError_t upload_gemm_w(DevBuf& d, const std::vector<float>& v, long N, long K, int dtype, bool x2) {
+    return x2 ? upload_f16_hi_lo(d, v, N, K) : upload_cvt(d, v, dtype);
+}
+
 // S3ENC_F32X3: upload the pair-packed bf16 hi / lo image of an (N, K) fp32 weight (K % 32 == 0, else left empty: that
 // GEMM then runs on the exact kernel)
 inline hipError_t upload_x3(DevBuf& d, const std::vector<float>& v, long N, long K) {
@@ -232,6 +251,7 @@ struct s3enc_encoder {
     int device = 0;
     int dtype = F32;
     bool x3 = false;  // S3ENC_F32X3
+    bool x2 = false;  // S3ENC_F16X2: fp16 data flow, GEMM weights as [hi | lo] fp16 halves (GemmParams.wsplit)
     int es = 4;  // element size of the compute dtype
     std::vector<ConvW> conv;
     DevBuf gn_g, gn_b;
@@ -339,6 +359,12 @@ struct Prof {
         if (idx >= 0) (void)hipEventRecord(e->recs[idx].b, st);
     }
 };
+
+// S3ENC_F16X2: every GEMM of the handle runs on its [hi | lo] weight rows
+inline GemmParams wsplit_of(const s3enc_encoder* e, GemmParams g) {
+    g.wsplit = e->x2 ? 1 : 0;
+    return g;
+}
 
 long conv_len(const s3enc_config& c, long n, int upto /*exclusive*/);  // frames after the first `upto` conv layers
 int valid_frames(const s3enc_config& c, long length, long n_max);      // un-masked frames under the family's mask rule

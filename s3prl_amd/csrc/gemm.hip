@@ -94,7 +94,9 @@ __global__ __launch_bounds__(256, ROWB == 128 ? 2 : (GLDS ? 5 : 3)) void gemm_ke
     const int m0 = tm * BM, n0 = tn * BN;
 
     const long lda_b = p.lda * EB;
-    const long kbytes = (long)p.K * EB;  // bytes of one full row of K
+    const long ka_bytes = (long)p.K * EB;                  // bytes of A's K extent
+    const long kbytes = p.wsplit ? 2 * ka_bytes : ka_bytes;  // bytes of the contraction ([hi | lo] weights: launcher checks K % stage)
+    const long ldw_b = p.ldw ? p.ldw * EB : kbytes;          // W row stride
     const char* Ab = (const char*)p.A + (long)b * p.a_bs * EB;
     const char* Wb = (const char*)p.W;
     const int nk = (int)((kbytes + ROWB - 1) / ROWB);
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(256, ROWB == 128 ? 2 : (GLDS ? 5 : 3)) void gemm_ke
         int rw = n0 + lr + RPT * i;
         rw = rw < p.N ? rw : p.N - 1;
         a_ptr[i] = Ab + (long)ra * lda_b + ls * 16;
-        w_ptr[i] = Wb + (long)rw * kbytes + ls * 16;
+        w_ptr[i] = Wb + (long)rw * ldw_b + ls * 16;
     }
     const int st_off = lr * ROWB + (ps << 4);  // + i*RPT*ROWB ; == tid*16 + i*4096
 
@@ -165,11 +167,12 @@ __global__ __launch_bounds__(256, ROWB == 128 ? 2 : (GLDS ? 5 : 3)) void gemm_ke
         };
         auto issue = [&](int kt, int stage) {
             const long kb = (long)kt * ROWB;
+            const long kba = kb >= ka_bytes ? kb - ka_bytes : kb;  // wsplit: the lo half re-reads A
             const unsigned sa = lds0 + stage * STAGE_BYTES;  // == st_off - lane*16
             const unsigned sw = sa + BM * ROWB;
 #pragma unroll
             for (int i = 0; i < NLD; ++i) {
-                dma(a_ptr[i] + kb, sa + i * 4096);
+                dma(a_ptr[i] + kba, sa + i * 4096);
                 dma(w_ptr[i] + kb, sw + i * 4096);
             }
         };
@@ -188,10 +191,11 @@ __global__ __launch_bounds__(256, ROWB == 128 ? 2 : (GLDS ? 5 : 3)) void gemm_ke
         uint4 ga[NLD], gw[NLD];
         auto load_tile = [&](int kt) {
             const long kb = (long)kt * ROWB;
+            const long kba = kb >= ka_bytes ? kb - ka_bytes : kb;
             const bool ok = kb + ls * 16 < kbytes;
 #pragma unroll
             for (int i = 0; i < NLD; ++i) {
-                ga[i] = ok ? *(const uint4*)(a_ptr[i] + kb) : make_uint4(0, 0, 0, 0);
+                ga[i] = ok ? *(const uint4*)(a_ptr[i] + kba) : make_uint4(0, 0, 0, 0);
                 gw[i] = ok ? *(const uint4*)(w_ptr[i] + kb) : make_uint4(0, 0, 0, 0);
             }
         };
@@ -324,6 +328,11 @@ hipError_t launch_gemm(int dtype, const GemmParams& p0, hipStream_t stream) {
     GemmParams p = p0;
     if (p.variant < 0) p.variant = tuning().gemm_variant;  // default 3: 64-byte stages + LDS-DMA (register staging for a ragged K)
     if (p.M <= 0 || p.N <= 0 || p.batches <= 0) return hipSuccess;
+    if (p.wsplit) {
+        if (dtype == F32) return hipErrorInvalidValue;
+        if (!p.ldw) p.ldw = 2L * p.K;
+        if (((long)p.K * 2) & 127) p.wsplit = 0;  // the lo half must start on a stage boundary: else this GEMM runs on hi alone
+    }
     if (dtype == F32 && gemm_x3_eligible(p)) {
         if (gemm_tile_eligible(3, p)) return launch_gemm_tile(3, p, stream);
         return launch_gemm_x3(p, stream);
@@ -342,6 +351,7 @@ hipError_t launch_gemm(int dtype, const GemmParams& p0, hipStream_t stream) {
         (((uintptr_t)p.W) & 15))
         return hipErrorInvalidValue;
     dim3 grid(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.batches);
+    if (p.ldw && (((p.ldw * eb) & 15))) return hipErrorInvalidValue;
     const bool a64 = (((long)p.K * eb) & 63) == 0, a128 = (((long)p.K * eb) & 127) == 0;
     switch (dtype) {
         case F32: return gemm_variant<float>(p, grid, stream, a64, a128);

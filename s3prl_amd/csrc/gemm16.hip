@@ -35,6 +35,16 @@
 
 #include "kernels.h"
 
+// Timing probes (garbage results by design; compiled in only by tools/micro/gemm16_lab.hip): GemmParams.variant bit 4 = the
+// epilogue computes but does not store, bit 5 = no epilogue at all, bit 6 = no K loop (epilogue of zeros only)
+#if defined(S3_GEMM_PROBE) && defined(__HIP_DEVICE_COMPILE__)
+#define S3_GPROBE(p_, bit_) ((p_).variant & (bit_))
+#define S3_GKEEP4(v_) asm volatile("" ::"v"((v_).x), "v"((v_).y), "v"((v_).z), "v"((v_).w))
+#else
+#define S3_GPROBE(p_, bit_) 0
+#define S3_GKEEP4(v_) ((void)0)
+#endif
+
 namespace s3 {
 
 namespace {
@@ -93,10 +103,12 @@ __global__ __launch_bounds__(128 * WN, WPE) void gemm16_big_kernel(GemmParams p)
     const int m0 = tm * BM, n0 = tn * BN;
 
     const long lda_b = p.lda * 2;
-    const long kbytes = (long)p.K * 2;
+    const long kbytes = (long)p.K * 2;                      // bytes of A's K extent
+    const long wk = p.wsplit ? 2 * kbytes : kbytes;        // bytes of the contraction: [hi | lo] weights run A twice
+    const long ldw_b = p.ldw ? p.ldw * 2 : wk;              // W row stride
     const char* Ab = (const char*)p.A + (long)b * p.a_bs * 2;
     const char* Wb = (const char*)p.W;
-    const int nk = (int)(kbytes / ROWB);
+    const int nk = (int)(wk / ROWB);
 
     // ---- loader: lane (lr, ps) fills physical 16-byte slot ps of row lr (+64 per pass) and FETCHES the logical slot
     //      ps ^ swizzle(row): 8 lanes read one whole 128-byte line of a row ----
@@ -115,7 +127,7 @@ __global__ __launch_bounds__(128 * WN, WPE) void gemm16_big_kernel(GemmParams p)
     for (int i = 0; i < NLB; ++i) {
         int rw = ((p.variant & 8) ? 0 : n0) + lr + RPP * i;
         rw = rw < p.N ? rw : p.N - 1;
-        w_ptr[i] = Wb + (long)rw * kbytes + ls * 16;
+        w_ptr[i] = Wb + (long)rw * ldw_b + ls * 16;
     }
     // LDS-DMA issued from inline asm: hipcc does not count it, so it inserts no vmcnt(0) in front of the fragment
     // ds_reads of the stage being multiplied (with the builtin it does — the DMA is a pending LDS write it cannot
@@ -135,8 +147,9 @@ __global__ __launch_bounds__(128 * WN, WPE) void gemm16_big_kernel(GemmParams p)
     constexpr int NL = NLA + NLB;
     auto issue_piece = [&](int pc, int kt, int stage) {
         const long kb = (long)kt * ROWB;
+        const long kba = kb >= kbytes ? kb - kbytes : kb;    // (wsplit: the lo half re-reads A from its start; K % 64 == 0)
         const unsigned sa = lds_base + stage * STAGE_BYTES;  // wave-uniform; lane l lands at + l*16
-        if (pc < NLA) glds16(a_ptr[pc] + kb, sa + pc * PASS_BYTES);
+        if (pc < NLA) glds16(a_ptr[pc] + kba, sa + pc * PASS_BYTES);
         else glds16(w_ptr[pc - NLA] + kb, sa + A_BYTES + (pc - NLA) * PASS_BYTES);
     };
     auto issue = [&](int kt, int stage) {
@@ -195,7 +208,8 @@ __global__ __launch_bounds__(128 * WN, WPE) void gemm16_big_kernel(GemmParams p)
         }
     };
 
-    if constexpr (NST == 2) {
+    if (S3_GPROBE(p, 64)) {
+    } else if constexpr (NST == 2) {
         issue(0, 0);
         barrier_all();  // stage 0 is visible to every wave
         for (int kt = 0; kt < nk; ++kt) {
@@ -220,6 +234,15 @@ __global__ __launch_bounds__(128 * WN, WPE) void gemm16_big_kernel(GemmParams p)
         }
     }
 
+#if defined(S3_GEMM_PROBE) && defined(__HIP_DEVICE_COMPILE__)
+    if (S3_GPROBE(p, 32)) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[i][j]));
+        return;
+    }
+#endif
     // ---- epilogue through a wave-private LDS transpose: 32 x 64 fp32 per step ----
     // Specialised at compile time on (GELU, residual, fp32 out, 16-bit out) for the four combinations the encoder uses
     // — the generic form tests five uniform flags per 4-row pass (168 branches per tile) — with a generic fallback.
@@ -273,8 +296,10 @@ __global__ __launch_bounds__(128 * WN, WPE) void gemm16_big_kernel(GemmParams p)
                                 gelu_fast4(w);
                             }
                             const long o = ob + (long)m * p.ldo + n8;
-                            *(uint4*)((store_t*)p.out16 + o) = make_uint4(Cvt<T>::pack2(v.x, v.y), Cvt<T>::pack2(v.z, v.w),
-                                                                          Cvt<T>::pack2(w.x, w.y), Cvt<T>::pack2(w.z, w.w));
+                            const uint4 pk = make_uint4(Cvt<T>::pack2(v.x, v.y), Cvt<T>::pack2(v.z, v.w), Cvt<T>::pack2(w.x, w.y),
+                                                        Cvt<T>::pack2(w.z, w.w));
+                            if (S3_GPROBE(p, 16)) S3_GKEEP4(pk);
+                            else *(uint4*)((store_t*)p.out16 + o) = pk;
                         }
                     }
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -306,8 +331,12 @@ __global__ __launch_bounds__(128 * WN, WPE) void gemm16_big_kernel(GemmParams p)
                         v.x += rs.x; v.y += rs.y; v.z += rs.z; v.w += rs.w;
                     }
                     if (!SPEC && m >= limit) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (o32) *(float4*)(p.out32 + o) = v;
-                    if (o16) *(uint2*)((store_t*)p.out16 + o) = make_uint2(Cvt<T>::pack2(v.x, v.y), Cvt<T>::pack2(v.z, v.w));
+                    if (S3_GPROBE(p, 16)) {
+                        S3_GKEEP4(v);
+                    } else {
+                        if (o32) *(float4*)(p.out32 + o) = v;
+                        if (o16) *(uint2*)((store_t*)p.out16 + o) = make_uint2(Cvt<T>::pack2(v.x, v.y), Cvt<T>::pack2(v.z, v.w));
+                    }
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -59,6 +59,11 @@ struct GemmParams {
     void* out16;
     long ldo, o_bs;
     int variant = -1;  // tuning knob: -1 = the current tuning().gemm_variant
+    // 16-bit modes: W row stride in elements (0 = K, or 2K with wsplit) and the two-term weight split of S3ENC_F16X2:
+    // every W row is [hi(K) | lo(K)] with w = hi + lo (two fp16), and the contraction runs over 2K with A read twice:
+    //   sum_k a[k] * hi[k] + sum_k a[k] * lo[k]   — the weights' rounding error disappears at twice the matrix cost
+    long ldw = 0;
+    int wsplit = 0;
 };
 // gemm_x3.hip: fp32-class GEMM from three bf16 MFMAs per product (opt-in compute mode S3ENC_F32X3)
 bool gemm_x3_eligible(const GemmParams& p);

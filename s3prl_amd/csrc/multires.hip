@@ -218,7 +218,7 @@ int multires_tail(s3enc_handle e, hipStream_t st, int B, const MrPlan& plan, con
                 g.ldo = 3 * D;
                 if (dt == F32) g.out32 = (float*)qkv; else g.out16 = qkv;
                 Prof pr(e, st, "gemm:qkv", 2.0 * gM * 3 * D * D, (gM * D + 3.0 * D * D + gM * 3 * D) * es);
-                HIP_TRY(launch_gemm(dt, g, st));
+                HIP_TRY(launch_gemm(dt, wsplit_of(e, g), st));
             }
             {
                 AttnParams a{};
@@ -246,7 +246,7 @@ int multires_tail(s3enc_handle e, hipStream_t st, int B, const MrPlan& plan, con
                 g.residual = cur;
                 g.out32 = tmp1;
                 Prof pr(e, st, "gemm:out_proj", 2.0 * gM * D * D, (gM * D + (double)D * D) * es + gM * D * 8);
-                HIP_TRY(launch_gemm(dt, g, st));
+                HIP_TRY(launch_gemm(dt, wsplit_of(e, g), st));
             }
             const float* ffn_res;
             const void* ffn_in;
@@ -278,7 +278,7 @@ int multires_tail(s3enc_handle e, hipStream_t st, int B, const MrPlan& plan, con
                 g.ldo = F;
                 if (dt == F32) g.out32 = (float*)hbuf; else g.out16 = hbuf;
                 Prof pr(e, st, "gemm:fc1", 2.0 * gM * F * D, (gM * D + (double)F * D + gM * F) * es);
-                HIP_TRY(launch_gemm(dt, g, st));
+                HIP_TRY(launch_gemm(dt, wsplit_of(e, g), st));
             }
             float* nxt = (!prel && lastl) ? y_out : pick(cur);
             {
@@ -296,7 +296,7 @@ int multires_tail(s3enc_handle e, hipStream_t st, int B, const MrPlan& plan, con
                 g.residual = ffn_res;
                 g.out32 = prel ? nxt : tmp1;
                 Prof pr(e, st, "gemm:fc2", 2.0 * gM * D * F, (gM * F + (double)D * F) * es + gM * D * 8);
-                HIP_TRY(launch_gemm(dt, g, st));
+                HIP_TRY(launch_gemm(dt, wsplit_of(e, g), st));
             }
             if (!prel) {
                 Prof pr(e, st, "layernorm:ln2", 0, gM * D * (8 + (dt == F32 ? 0 : es)));
@@ -354,7 +354,7 @@ int multires_tail(s3enc_handle e, hipStream_t st, int B, const MrPlan& plan, con
             // algorithmic flops: the k real taps (the zero taps that square up the transposed conv's phases are not counted)
             Prof pr(e, st, "gemm:adapter", 2.0 * B * (transposed ? (double)rows : (double)Mrows) * D * D * k,
                     ((double)B * total * D + (double)g.N * g.K) * es + (double)B * *frames * D * 4);
-            HIP_TRY(launch_gemm(dt, g, st));
+            HIP_TRY(launch_gemm(dt, wsplit_of(e, g), st));
         }
         Prof pr(e, st, "adapter_stats", 0, (double)B * *frames * D * 4);
         HIP_TRY(launch_group1_stats(convout, *frames * D, *frames * D, B, gpart, st));

@@ -78,6 +78,11 @@ int s3enc_op_gemm(int32_t dtype, const void* A, int64_t lda, int64_t a_batch_str
     g.out16 = out16;
     g.ldo = ldo;
     g.o_bs = o_batch_stride;
+    if (dtype == 4) {  // S3ENC_F16X2: fp16 A, W given as (N, 2K) fp16 rows [hi(K) | lo(K)] — the contraction runs over both
+        g.wsplit = 1;
+        HIP_TRY(launch_gemm(F16, g, (hipStream_t)stream));
+        return 0;
+    }
     if (dtype == 3) {  // S3ENC_F32X3: fp32 operands; W is split into its pair-packed bf16 hi / lo image here
         if (K % 32) return fail("s3enc_op_gemm: S3ENC_F32X3 needs K % 32 == 0");
         // tuning key "x3_pack_cache" (micro-benchmarks only): keep the packed image of the last (W, N, K) and skip the

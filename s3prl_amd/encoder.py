@@ -125,7 +125,9 @@ class HipEncoder:
         tdt, code = torch.float32, _lib.F32
         if out_dtype not in (None, "fp32", "f32", "float32"):
             code = _lib.DTYPES[out_dtype]
-            if code != _lib.DTYPES[self.dtype] or code not in (_lib.BF16, _lib.F16):
+            own = _lib.DTYPES[self.dtype]
+            own = _lib.F16 if own == _lib.F16X2 else own  # the two-term split mode runs the fp16 data flow
+            if code != own or code not in (_lib.BF16, _lib.F16):
                 raise ValueError(f"out_dtype {out_dtype!r}: only fp32 or the encoder's own 16-bit compute dtype ({self.dtype})")
             tdt = torch.bfloat16 if code == _lib.BF16 else torch.float16
         if out is None:

@@ -202,6 +202,49 @@ def _attention_ref(qkv, valid, B, T, H, table=None, gate=None, R=None):
     return (p @ v).transpose(0, 2, 1, 3).reshape(B * T, D)
 
 
+@pytest.mark.parametrize("shape", [(1, 700, 516, 320, 1, True), (2, 530, 264, 128, 0, False), (1, 129, 132, 64, 0, False),
+                                   (1, 1000, 768, 3072, 1, False)])
+def test_gemm_f16x2_two_term_weights(shape):
+    """S3ENC_F16X2 at the op level: fp16 A, W as [hi | lo] fp16 halves per row, the K loop runs over 2K with A read twice.
+    With A already fp16-exact the result must match the float64 product with the UNROUNDED weights to fp32-accumulation
+    level — the weights' fp16 rounding error (5e-4 relative per weight) is gone — on the large-tile kernel and on the
+    128x128 fallback (small shapes), with GELU / residual epilogues."""
+    torch = _torch()
+    from s3prl_amd import _lib
+
+    lib = _lib.load()
+    batches, M, N, K, act, use_res = shape
+    rng = np.random.default_rng(zlib.crc32(repr(shape).encode()))
+    A = _round(rng.standard_normal((batches, M, K)).astype(np.float32), "fp16")
+    W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    res = rng.standard_normal((batches, M, N)).astype(np.float32)
+    y = A.astype(np.float64) @ W.astype(np.float64).T + bias
+    if act:
+        y = O.gelu(y)
+    if use_res:
+        y = y + res
+    Wt = torch.from_numpy(W)
+    hi = Wt.half()
+    lo = (Wt - hi.float()).half()
+    W2 = torch.cat([hi, lo], dim=1).contiguous().cuda()  # (N, 2K)
+    dA, dbias, dres = _dev(A, "fp16"), _dev(bias), _dev(res)
+    out = torch.full((batches, M, N), float("nan"), device="cuda")
+    rc = lib.s3enc_op_gemm(4, _ptr(dA), K, M * K, _ptr(W2), _ptr(dbias), M, N, K, batches, act, _ptr(dres) if use_res else None, None,
+                           _ptr(out), None, N, M * N, None)
+    _lib.check(rc, "s3enc_op_gemm f16x2")
+    torch.cuda.synchronize()
+    err = O.rel_err(out.cpu().numpy(), y)
+    assert err < 2e-6, f"f16x2 gemm {shape}: rel-err {err:.3e}"
+    # the same A against the fp16-ROUNDED weights alone (what S3ENC_F16 computes) is two orders worse
+    out1 = torch.full((batches, M, N), float("nan"), device="cuda")
+    dW1 = hi.contiguous().cuda()
+    _lib.check(lib.s3enc_op_gemm(2, _ptr(dA), K, M * K, _ptr(dW1), _ptr(dbias), M, N, K, batches, act,
+                                 _ptr(dres) if use_res else None, None, _ptr(out1), None, N, M * N, None), "s3enc_op_gemm f16")
+    torch.cuda.synchronize()
+    assert O.rel_err(out1.cpu().numpy(), y) > 20 * err
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16", "fp32x3"])
 @pytest.mark.parametrize("T,rel", [(33, False), (200, False), (149, 200), (499, False), (300, 40), (749, 800)])
 def test_attention(dtype, T, rel):

@@ -1,0 +1,77 @@
+// gemm16_lab — timing probes of the 16-bit lock-step GEMM (gemm16.hip compiled here with S3_GEMM_PROBE): how much of a launch is
+// the K loop, the epilogue's LDS / VALU part, and the global stores (+ their drain before the workgroup can retire)?
+// Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -DS3_GEMM_PROBE -Is3prl_amd/csrc tools/micro/gemm16_lab.hip -o tools/micro/gemm16_lab
+#include "../../s3prl_amd/csrc/gemm16.hip"
+
+#include <cstdio>
+#include <vector>
+
+namespace s3 {
+Tuning g_tuning;
+thread_local const Tuning* t_tuning = nullptr;
+}  // namespace s3
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+__global__ void fill16(unsigned short* p, long n, unsigned seed, float scale) {
+    long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    for (; i < n; i += (long)gridDim.x * blockDim.x) {
+        unsigned x = (unsigned)i * 2654435761u + seed;
+        x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+        const float f = ((int)(x & 0xffffff) - 0x800000) * (scale / 0x800000);
+        p[i] = (unsigned short)(__float_as_uint(f) >> 16);
+    }
+}
+
+int main() {
+    struct Shape { const char* name; int M, N, K, act, res; };
+    const Shape shapes[] = {{"qkv 15968x2304x768", 15968, 2304, 768, 0, 0}, {"out_proj 15968x768x768", 15968, 768, 768, 0, 1},
+                            {"fc1 15968x3072x768", 15968, 3072, 768, 1, 0}, {"fc2 15968x768x3072", 15968, 768, 3072, 0, 1},
+                            {"L.fc1 15968x4096x1024", 15968, 4096, 1024, 1, 0}};
+    const int probes[] = {0, 16, 32, 64, 64 | 16};
+    const char* names[] = {"product", "no global stores", "no epilogue", "no K loop", "no K loop, no stores"};
+    hipStream_t st;
+    CK(hipStreamCreate(&st));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    for (const Shape& sh : shapes) {
+        unsigned short *A, *W, *o16;
+        float *bias, *res, *o32;
+        const long mn = (long)sh.M * sh.N;
+        CK(hipMalloc(&A, (long)sh.M * sh.K * 2 + 256));
+        CK(hipMalloc(&W, (long)sh.N * sh.K * 2));
+        CK(hipMalloc(&o16, mn * 2));
+        CK(hipMalloc(&o32, mn * 4));
+        CK(hipMalloc(&res, mn * 4));
+        CK(hipMalloc(&bias, sh.N * 4));
+        fill16<<<2048, 256, 0, st>>>(A, (long)sh.M * sh.K, 1u, 1.0f);
+        fill16<<<2048, 256, 0, st>>>(W, (long)sh.N * sh.K, 2u, 0.05f);
+        CK(hipMemsetAsync(bias, 0, sh.N * 4, st));
+        CK(hipMemsetAsync(res, 0, mn * 4, st));
+        const double flops = 2.0 * sh.M * (double)sh.N * sh.K;
+        printf("\n%s  bf16 (act %d, residual %d)\n\n| probe | us per launch | TFLOP/s |\n|---|---:|---:|\n", sh.name, sh.act, sh.res);
+        for (size_t i = 0; i < sizeof(probes) / sizeof(probes[0]); ++i) {
+            s3::GemmParams p{};
+            p.A = A; p.lda = sh.K; p.a_bs = 0; p.W = W; p.bias = bias; p.M = sh.M; p.N = sh.N; p.K = sh.K; p.batches = 1;
+            p.act = sh.act; p.residual = sh.res ? res : nullptr; p.row_limit = nullptr;
+            p.out32 = sh.res ? o32 : nullptr; p.out16 = sh.res ? nullptr : (void*)o16; p.ldo = sh.N; p.o_bs = mn;
+            p.variant = 3 | probes[i];
+            double best = 1e30;
+            for (int r = 0; r < 3; ++r) {
+                CK(s3::launch_gemm16_big(s3::BF16, p, st));
+                CK(hipEventRecord(e0, st));
+                for (int k = 0; k < 40; ++k) CK(s3::launch_gemm16_big(s3::BF16, p, st));
+                CK(hipEventRecord(e1, st));
+                CK(hipEventSynchronize(e1));
+                float ms;
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                best = ms / 40 < best ? ms / 40 : best;
+            }
+            printf("| %s | %.1f | %.0f |\n", names[i], best * 1e3, flops / best * 1e-9);
+            fflush(stdout);
+        }
+        CK(hipFree(A)); CK(hipFree(W)); CK(hipFree(o16)); CK(hipFree(o32)); CK(hipFree(res)); CK(hipFree(bias));
+    }
+    return 0;
+}

@@ -18,14 +18,14 @@ print("# Parity of the HIP encoder vs outputs of the reference itself (tests/gol
 print()
 print("max / mean over the hidden states of the per-layer relative error ||h - h_ref||_F / ||h_ref||_F (SURVEY §8d); target 1e-3.")
 print()
-print("| fixture | shape | fp32 | fp32x3 | fp16 | bf16 |")
-print("|---|---|---:|---:|---:|---:|")
+print("| fixture | shape | fp32 | fp32x3 | fp16x2 | fp16 | bf16 |")
+print("|---|---|---:|---:|---:|---:|---:|")
 for name in names:
     meta, cfg, weights, wavs, golden, _ = load_golden(name)
     dev = [torch.from_numpy(w).cuda() for w in wavs]
     ts, cs = meta["t_stride"], meta["c_stride"]
     cells = []
-    for mode in ("fp32", "fp32x3", "fp16", "bf16"):
+    for mode in ("fp32", "fp32x3", "fp16x2", "fp16", "bf16"):
         enc = HipEncoder(cfg, weights, dtype=mode)
         hs = enc.forward(dev, selection=meta.get("selection")).cpu().numpy()
         errs = [O.rel_err(hs[l][:, ::ts, ::cs], golden[l]) for l in range(len(golden))]
