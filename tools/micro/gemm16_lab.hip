@@ -4,6 +4,7 @@
 #include "../../s3prl_amd/csrc/gemm16.hip"
 
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 namespace s3 {
@@ -23,7 +24,9 @@ __global__ void fill16(unsigned short* p, long n, unsigned seed, float scale) {
     }
 }
 
-int main() {
+int main(int argc, char** argv) {
+    s3::g_tuning.gemm16_big = argc > 1 ? atoi(argv[1]) : 3;  // 3 = default (lock-step 256x256 / 192x256), 4 = 128x256 ring, two per CU
+    printf("gemm16_big mode %d\n", s3::g_tuning.gemm16_big);
     struct Shape { const char* name; int M, N, K, act, res; };
     const Shape shapes[] = {{"qkv 15968x2304x768", 15968, 2304, 768, 0, 0}, {"out_proj 15968x768x768", 15968, 768, 768, 0, 1},
                             {"fc1 15968x3072x768", 15968, 3072, 768, 1, 0}, {"fc2 15968x768x3072", 15968, 768, 3072, 0, 1},
