@@ -4,17 +4,21 @@
 // (w = g * v / ||v||, dim=2) is folded at pack time.
 //
 // Per group this is a Toeplitz GEMM: out[t][co] = sum_{j<K} sum_{ci<Dg} x[t + j - K/2][ci] * w[co][ci][j].
-// One workgroup = (batch b, group g, 64 output frames).  The (64 + K - 1) x Dg input window of the group is staged
-// ONCE in LDS (the 128-frame halo is re-used by all 128 taps — the A operand of tap j is just the window shifted by
-// j rows), the Dg x Dg weight slice of tap j streams through a double-buffered LDS tile shared by the 4 waves, and each
-// wave accumulates 16 frames x Dg channels with v_mfma_f32_16x16x4_f32 (exact fp32).  Residual add, bias and erf-GELU
-// are fused in the epilogue; x is read once and the (B,T,D) result written once.
+// One workgroup = (batch b, group g, 128 output frames).  The (128 + K - 1) x Dg input window of the group is staged
+// ONCE in LDS (the halo is re-used by all 128 taps — the A operand of tap j is just the window shifted by j rows), the
+// Dg x Dg weight slice of tap j streams through a double-buffered LDS tile shared by the 4 waves, and each wave
+// accumulates 32 frames x Dg channels with v_mfma_f32_16x16x4_f32 (exact fp32): 2 x Dg/16 independent accumulator chains
+// per wave (the 16x16x4 shape needs >= 6-8 in flight to approach its rate: profiles/r02_mfma_peak.md) and every weight
+// fragment read from LDS feeds two frame tiles.  Residual add, bias and erf-GELU are fused in the epilogue; x is read
+// once and the (B,T,D) result written once.  (Round 3: 64 -> 128 frames per workgroup = half the weight stream per output,
+// and the XCD-aware work map below keeps each group's 1.2 MB weight slice in ONE L2.)
 #include "kernels.h"
 
 namespace s3 {
 namespace {
 
-constexpr int PC_TM = 64;  // output frames per workgroup
+constexpr int PC_TM = 128;  // output frames per workgroup (4 waves x 2 frame tiles of 16)
+constexpr int PC_FT = 2;    // 16-frame tiles per wave
 
 // XCD-aware work map (1-D grid; workgroup w runs on XCD w % 8, each with a private 4 MiB L2).  Every workgroup of a group
 // streams that group's whole weight slice (Dg x Dg x K: 1.2 MB fp32 at HuBERT-base); with the plain (frame tile, group,
@@ -95,25 +99,34 @@ __global__ __launch_bounds__(256) void posconv_kernel(PosConvParams p) {
     wstore(0);
     __syncthreads();
 
-    f32x4 acc[NT];
+    f32x4 acc[PC_FT][NT];
 #pragma unroll
-    for (int n = 0; n < NT; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int f = 0; f < PC_FT; ++f)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[f][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const float* xrow = xs + (wave * 16 + l15) * RS + 4 * kk;
+    const float* xrow = xs + (wave * (16 * PC_FT) + l15) * RS + 4 * kk;  // frame tile f: + 16 f rows
     for (int j = 0; j < K; ++j) {
         if (j + 1 < K) wload(j + 1);
         const float* wb = wl + (j & 1) * WSZ + l15 * 16 + 4 * kk;
         const float* xa = xrow + j * RS;
 #pragma unroll
         for (int cc = 0; cc < NCC; ++cc) {
-            const float4 a = *(const float4*)(xa + 16 * cc);
+            float4 a[PC_FT];
+#pragma unroll
+            for (int f = 0; f < PC_FT; ++f) a[f] = *(const float4*)(xa + f * 16 * RS + 16 * cc);
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
                 const float4 w = *(const float4*)(wb + (cc * DG + n * 16) * 16);
-                acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w.x, acc[n], 0, 0, 0);
-                acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w.y, acc[n], 0, 0, 0);
-                acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w.z, acc[n], 0, 0, 0);
-                acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w.w, acc[n], 0, 0, 0);
+                // per accumulator the k order is x, y, z, w of chunk cc, chunks and taps ascending — as before: a frame's
+                // result does not depend on the frame tile it sits in
+#pragma unroll
+                for (int f = 0; f < PC_FT; ++f) {
+                    acc[f][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[f].x, w.x, acc[f][n], 0, 0, 0);
+                    acc[f][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[f].y, w.y, acc[f][n], 0, 0, 0);
+                    acc[f][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[f].z, w.z, acc[f][n], 0, 0, 0);
+                    acc[f][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[f].w, w.w, acc[f][n], 0, 0, 0);
+                }
             }
         }
         if (j + 1 < K) wstore((j + 1) & 1);
@@ -122,18 +135,20 @@ __global__ __launch_bounds__(256) void posconv_kernel(PosConvParams p) {
 
     // D layout of 16x16: col = lane&15 (channel), row = 4*(lane>>4) + reg (frame)
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        const int c = g * DG + n * 16 + l15;
-        const float bias = p.bias[c];
+    for (int f = 0; f < PC_FT; ++f)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int t = t0 + wave * 16 + 4 * kk + r;
-            if (t < p.T) {
-                const long o = ((long)b * p.T + t) * p.D + c;
-                p.out[o] = p.plain ? acc[n][r] + bias : p.x[o] + gelu_erf(acc[n][r] + bias);
+        for (int n = 0; n < NT; ++n) {
+            const int c = g * DG + n * 16 + l15;
+            const float bias = p.bias[c];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int t = t0 + wave * (16 * PC_FT) + 16 * f + 4 * kk + r;
+                if (t < p.T) {
+                    const long o = ((long)b * p.T + t) * p.D + c;
+                    p.out[o] = p.plain ? acc[f][n][r] + bias : p.x[o] + gelu_erf(acc[f][n][r] + bias);
+                }
             }
         }
-    }
 }
 
 template <int DG>
