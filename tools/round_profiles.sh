@@ -1,47 +1,59 @@
 #!/bin/bash
 # Re-create the measured artefacts of a round on the GPU box (run through gpurun from the repo root):
-#   benches of the BASELINE configs (each with its parity leg), the rocprofv3 kernel-trace summary of the headline
-#   command, the PMC passes, the parity table.   usage: tools/round_profiles.sh r02
+#   per BASELINE config: PMC passes (-> profiles/traffic.json record) -> bench (its JSON then carries roofline.traffic) ->
+#   rocprofv3 kernel-trace summary; the operand modes of the headline workload; the micro labs; the parity table.
+# Raw rocprof output stays on the box (only the summaries are merged back: gpurun_out is capped at 64 MiB).
+# usage: tools/round_profiles.sh r03        (most important artefacts first: a cut-off run still leaves them)
 set -u
-tag=${1:-r02}
+tag=${1:-r03}
 export TMPDIR=/tmp
 out=gpurun_out/$tag
 mkdir -p $out
-python bench.py > $out/bench_fp32.json 2> $out/bench_fp32.err
-python bench.py --dtype bf16 --no-cpu-baseline > $out/bench_bf16.json 2>/dev/null
-python bench.py --dtype fp16 --no-cpu-baseline --steps 200 > $out/bench_fp16.json 2>/dev/null
-python bench.py --dtype fp32x3 --no-cpu-baseline > $out/bench_fp32x3.json 2>/dev/null
-python bench.py --model wav2vec2_base --no-cpu-baseline --steps 30 --warmup 2 > $out/bench_cfg1_wav2vec2_base_fp32.json 2>/dev/null
-python bench.py --model hubert_base --dtype bf16 --batch 64 --no-cpu-baseline --steps 100 --warmup 2 > $out/bench_cfg2_hubert_base_b64_bf16.json 2>/dev/null
-python bench.py --model hubert_large --dtype bf16 --no-cpu-baseline --steps 60 --warmup 2 > $out/bench_cfg3_hubert_large_bf16.json 2>/dev/null
-python bench.py --model hubert_large --dtype fp32x3 --no-cpu-baseline --steps 30 --warmup 2 > $out/bench_cfg3_hubert_large_fp32x3.json 2>/dev/null
-python bench.py --model hubert_large --dtype fp32 --no-cpu-baseline --steps 10 --warmup 1 > $out/bench_cfg3_hubert_large_fp32.json 2>/dev/null
-python bench.py --model wavlm_large --dtype bf16 --secs 15 --mixed --no-cpu-baseline --steps 40 --warmup 2 > $out/bench_cfg4_wavlm_large_mixed_bf16.json 2>/dev/null
-python bench.py --model wavlm_large --dtype fp32x3 --secs 15 --mixed --no-cpu-baseline --steps 15 --warmup 1 > $out/bench_cfg4_wavlm_large_mixed_fp32x3.json 2>/dev/null
-python bench.py --model wavlm_large --dtype fp32 --secs 15 --mixed --no-cpu-baseline --steps 6 --warmup 1 > $out/bench_cfg4_wavlm_large_mixed_fp32.json 2>/dev/null
-# the N-rank path, functionally, on this box's single GPU (ranks share the device over a gloo rendezvous): every exchange mode
-for g in layers featurized; do
-  python bench.py --gpus 2 --backend gloo --gather $g --steps 5 --warmup 1 --no-profile > $out/bench_2rank_gloo_$g.json 2>/dev/null
+Q="--no-cpu-baseline --no-other-modes"
+
+# one configuration: name, kernel substring of its dominant GEMM, model, dtype, batch, secs, extra bench flags, steps
+profile_cfg() {
+  local name=$1 sub=$2 model=$3 dtype=$4 batch=$5 secs=$6 extra=$7 steps=$8
+  local args="--model $model --dtype $dtype --batch $batch --secs $secs $extra"
+  PMC_GROUPS="sq1 sq2 tcc fetch write" tools/pmc.sh ${tag}_$name python bench.py $args --steps 2 --warmup 1 $Q --no-parity > /dev/null 2>&1
+  python tools/pmc_to_traffic.py gpurun_out/pmc_${tag}_$name $model $dtype $batch $secs profiles/traffic.json $sub > $out/traffic_$name.json 2>/dev/null
+  cp gpurun_out/pmc_${tag}_$name.md $out/pmc_$name.md 2>/dev/null
+  rm -rf gpurun_out/pmc_${tag}_$name gpurun_out/pmc_${tag}_$name.md
+  python bench.py $args --steps $steps --warmup 2 $Q > $out/bench_$name.json 2> $out/bench_$name.err
+  rocprofv3 --kernel-trace --stats -d /tmp/prof_$name -- python bench.py $args --steps 5 --warmup 1 $Q --no-parity > /dev/null 2>&1
+  db=$(find /tmp/prof_$name -name "*.db" | head -1)
+  [ -n "$db" ] && python tools/rocprof_summary.py "$db" $out/kernel_stats_$name.md > /dev/null
+  rm -rf /tmp/prof_$name
+  cp profiles/traffic.json $out/traffic.json
+}
+
+# 1. the metric's workload (HuBERT-base 32 x 10 s, fp32): PMC + traffic first so that the default bench line carries it
+profile_cfg fp32 gemm hubert_base fp32 32 10 "" 60
+python bench.py > $out/bench_fp32.json 2> $out/bench_fp32.err          # the default run: >= 5 s timed, CPU baseline, other modes
+# 2. BASELINE configs[2] / [3] / [4] exactly as named
+profile_cfg cfg2_hubert_base_b64_bf16 gemm16 hubert_base bf16 64 10 "" 100
+profile_cfg cfg3_hubert_large_bf16 gemm16 hubert_large bf16 32 10 "" 60
+profile_cfg cfg4_wavlm_large_mixed_bf16 gemm16 wavlm_large bf16 32 15 "--mixed" 40
+# 3. the operand modes of the headline workload
+profile_cfg bf16 gemm16 hubert_base bf16 32 10 "" 300
+python bench.py --dtype fp16x2 $Q > $out/bench_fp16x2.json 2>/dev/null
+python bench.py --dtype fp32x3 $Q > $out/bench_fp32x3.json 2>/dev/null
+python bench.py --dtype fp16 $Q --steps 200 > $out/bench_fp16.json 2>/dev/null
+# 4. the other modes of configs[1], [3], [4]
+python bench.py --model wav2vec2_base $Q --steps 30 --warmup 2 > $out/bench_cfg1_wav2vec2_base_fp32.json 2>/dev/null
+for d in fp16x2 fp32x3 fp32; do
+  python bench.py --model hubert_large --dtype $d $Q --steps 12 --warmup 1 > $out/bench_cfg3_hubert_large_$d.json 2>/dev/null
+  python bench.py --model wavlm_large --dtype $d --secs 15 --mixed $Q --steps 8 --warmup 1 > $out/bench_cfg4_wavlm_large_mixed_$d.json 2>/dev/null
 done
-python bench.py --gpus 2 --backend gloo --gather layers16 --dtype bf16 --steps 5 --warmup 1 --no-profile > $out/bench_2rank_gloo_layers16.json 2>/dev/null
-for d in fp32 fp32x3 bf16; do
-  python bench.py --model multires_hubert_base --dtype $d --no-cpu-baseline --steps 40 --warmup 3 > $out/bench_multires_hubert_base_$d.json 2>/dev/null
-done
-python tools/gemm_yardstick.py > $out/gemm_yardstick.md 2>/dev/null          # vendor BLAS beside the library's GEMMs (yardstick only)
-for m in mfma_peak gemm_loop_probe; do                                        # matrix-pipe ceilings and the fp32 loop's ingredients
-  [ -x tools/micro/$m ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 tools/micro/$m.hip -o tools/micro/$m 2>/dev/null
-  tools/micro/$m > $out/$m.md 2>/dev/null
-done
+# 5. micro labs (standalone binaries, seconds each)
+for b in gemm32_lab attn_lab gemm16_lab; do [ -x tools/micro/$b ] || echo "tools/micro/$b is not built" >&2; done
+tools/micro/gemm32_lab 3 > $out/gemm32_lab_fp32.md 2>&1
+tools/micro/gemm32_lab 3 - x3 > $out/gemm32_lab_x3.md 2>&1
+tools/micro/attn_lab > $out/attn_lab.md 2>&1
+tools/micro/gemm16_lab > $out/gemm16_lab.md 2>&1
+# 6. parity of every mode against the reference's own outputs
 python tools/parity_table.py > $out/parity.md 2> $out/parity.err
-# rocprofv3 kernel trace of the headline command (its own run: never combined with PMC passes)
-rocprofv3 --kernel-trace --stats -d $out/prof_fp32 -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-parity > $out/prof_fp32.log 2>&1
-db=$(find $out/prof_fp32 -name "*.db" | head -1)
-[ -n "$db" ] && python tools/rocprof_summary.py "$db" $out/kernel_stats_fp32.md > /dev/null
-rocprofv3 --kernel-trace --stats -d $out/prof_bf16 -- python bench.py --dtype bf16 --steps 5 --warmup 1 --no-cpu-baseline --no-parity > $out/prof_bf16.log 2>&1
-db=$(find $out/prof_bf16 -name "*.db" | head -1)
-[ -n "$db" ] && python tools/rocprof_summary.py "$db" $out/kernel_stats_bf16.md > /dev/null
-# PMC passes (traffic, MFMA-busy, waits) of the same command
-tools/pmc.sh ${tag}_fp32 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-parity > /dev/null 2>&1
-tools/pmc.sh ${tag}_bf16 python bench.py --dtype bf16 --steps 2 --warmup 1 --no-cpu-baseline --no-parity > /dev/null 2>&1
-rm -rf $out/prof_fp32 $out/prof_bf16   # keep the summaries, not the traces
+# 7. a sibling model and the N-rank path, functionally (two ranks share this box's single GPU over a gloo rendezvous)
+python bench.py --model multires_hubert_base $Q --steps 40 --warmup 3 > $out/bench_multires_hubert_base_fp32.json 2>/dev/null
+python bench.py --gpus 2 --backend gloo --gather layers --steps 5 --warmup 1 --no-profile > $out/bench_2rank_gloo_layers.json 2>/dev/null
 ls $out
