@@ -6,6 +6,11 @@
 #include <cstdio>
 #include <vector>
 
+namespace s3 {
+Tuning g_tuning;
+thread_local const Tuning* t_tuning = nullptr;
+}  // namespace s3
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
 __global__ void fill16(unsigned short* p, long n, unsigned seed, float scale) {
