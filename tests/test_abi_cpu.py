@@ -81,3 +81,35 @@ def test_no_gpu_means_loud_failure():
     cfg = named_config("tiny_hubert")
     with pytest.raises(_lib.S3EncError, match="no CPU fallback"):
         HipEncoder(cfg, synth_weights(cfg, 0))
+
+
+def test_tuning_keys_are_validated_process_wide_and_per_handle():
+    """s3enc_set_tuning / s3enc_set_handle_tuning share one key table: unknown keys and out-of-range values fail with a
+    message, a null handle fails, and the process-wide defaults stay what they were."""
+    _lib = _built()
+    lib = _lib.load()
+    assert lib.s3enc_set_tuning(b"gemm32_big", 1) == 0
+    assert lib.s3enc_set_tuning(b"gemm32_big", 99) != 0 and b"gemm32_big must be 0..5" in lib.s3enc_last_error()
+    assert lib.s3enc_set_tuning(b"no_such_key", 0) != 0 and b"unknown key" in lib.s3enc_last_error()
+    assert lib.s3enc_set_tuning(None, 0) != 0
+    assert lib.s3enc_set_handle_tuning(None, b"gemm32_big", 1) != 0 and b"null handle" in lib.s3enc_last_error()
+    for key in (b"gemm_variant", b"gemm_x3_tile", b"gemm16_big", b"attn_lds_pad", b"gemm_lds_pad", b"x3_pack_cache"):
+        assert lib.s3enc_set_tuning(key, 0) == 0, key
+    # restore the defaults other tests rely on
+    assert lib.s3enc_set_tuning(b"gemm_variant", 3) == 0 and lib.s3enc_set_tuning(b"gemm_x3_tile", 1) == 0
+    assert lib.s3enc_set_tuning(b"gemm16_big", 3) == 0
+
+
+def test_comm_entry_points_fail_cleanly_without_a_communicator():
+    """The RCCL exchange behind the C ABI: librccl is dlopen'ed on first use (its version is readable without a GPU); null
+    communicators / ids are rejected with a message instead of crashing."""
+    _lib = _built()
+    lib = _lib.load()
+    v = C.c_int32(0)
+    rc = lib.s3enc_comm_version(C.byref(v))
+    assert (rc == 0 and v.value > 20000) or b"librccl" in lib.s3enc_last_error()
+    assert lib.s3enc_comm_unique_id(None) != 0
+    out = C.c_void_p()
+    assert lib.s3enc_comm_init_rank(None, 1, 0, 0, C.byref(out)) != 0
+    assert lib.s3enc_comm_allgather_states(None, None, 0, None, 0, 1, 4, None, None) != 0
+    assert lib.s3enc_comm_destroy(None) == 0
