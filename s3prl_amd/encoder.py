@@ -124,9 +124,8 @@ class HipEncoder:
         NS = self.num_states(selection)
         tdt, code = torch.float32, _lib.F32
         if out_dtype not in (None, "fp32", "f32", "float32"):
-            code = _lib.DTYPES[out_dtype]
-            own = _lib.DTYPES[self.dtype]
-            own = _lib.F16 if own == _lib.F16X2 else own  # the two-term split mode runs the fp16 data flow
+            fold = lambda c: _lib.F16 if c == _lib.F16X2 else c  # the two-term split mode runs the fp16 data flow
+            code, own = fold(_lib.DTYPES[out_dtype]), fold(_lib.DTYPES[self.dtype])
             if code != own or code not in (_lib.BF16, _lib.F16):
                 raise ValueError(f"out_dtype {out_dtype!r}: only fp32 or the encoder's own 16-bit compute dtype ({self.dtype})")
             tdt = torch.bfloat16 if code == _lib.BF16 else torch.float16
