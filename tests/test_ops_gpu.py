@@ -499,7 +499,7 @@ def test_wavlm_gate_kernel():
     (2, 99, 2304, 768, 768, None, 0, False, False),      # a short utterance: the 64-row tile's home shape
 ])
 def test_gemm32_big_tile_is_bit_identical_to_the_default_kernel(shape):
-    """The fp32 path's default GEMM (gemm32big.hip: 256 / 192 / 128 / 64 x 128 tiles, tuning key gemm32_big = 2..5, 1 = chosen
+    """The fp32 path's default GEMM (gemmt.hip: 256 / 192 / 128 / 64 x 128 tiles, tuning key gemm32_big = 2..5, 1 = chosen
     per shape): same instruction and per-accumulator k order as gemm_kernel<float> (gemm32_big = 0), so every tile height and
     every epilogue feature must reproduce that kernel bit for bit — a row's rounding never depends on the tile choice."""
     torch = _torch()
