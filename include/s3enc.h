@@ -217,14 +217,17 @@ int s3enc_profile_read(s3enc_handle h, s3enc_profile_entry* entries, int32_t max
  * ("conv4".."conv6" for the 7-layer stack), "feat_ln", "proj", "posconv", "qkv0", "attn0".  Synchronises. */
 int s3enc_debug_tap(s3enc_handle h, const char* name, float* host_out, int64_t max_elems, int64_t* n_elems);
 
-/* Process-wide tuning knobs (kernel-variant selection for A/B measurements; results are unchanged):
+/* Process-wide tuning knobs (kernel-variant selection for A/B measurements; results are unchanged, except "gelu32"):
  *   "gemm_variant": gemm.hip's 128x128 kernel: bit 0 = 64-byte K stages (else 128), bit 1 = LDS-DMA staging, bit 2 = no
  *                   XCD-aware tile order;
  *   "gemm32_big":   exact-fp32 tile kernel (gemmt.hip): 0 off (gemm.hip), 1 = tile height by shape (default), 2 / 3 / 4 / 5 =
  *                   force 256 / 192 / 128 / 64 rows;  "gemm_x3_tile": the same for S3ENC_F32X3 (1 = only small shapes);
  *   "gemm16_big":   large-tile kernel of the 16-bit modes: 0 off, 1 = one workgroup per CU (256x256 or 192x256 tiles by CU
  *                   utilisation; 5 / 6 force either), 2 = 128x256, 4 = 128x256 with a 3-stage ring (two workgroups per
- *                   CU), 3 = chosen by shape (default). */
+ *                   CU), 3 = chosen by shape (default);
+ *   "gelu32":       S3ENC_F32 only: 1 = the one-transcendental erf-GELU every mode uses (default; csrc/common.h gelu_fast: as
+ *                   close to an fp64 erf-GELU as 0.5 x (1 + erff(x / sqrt 2)) evaluated in fp32), 0 = libm erff — results
+ *                   differ in the last bits. */
 int s3enc_set_tuning(const char* key, int32_t value);
 /* The same keys for ONE handle: the handle starts from the process-wide values as they are at the first call and keeps its own
  * copy from then on; its forwards use that copy (per calling thread), other handles and the s3enc_op_* entry points do not. */

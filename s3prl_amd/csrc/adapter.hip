@@ -224,7 +224,7 @@ hipError_t launch_adapter_apply(int dtype, const AdapterApplyParams& p, hipStrea
     if (p.B <= 0 || p.total <= 0) return hipSuccess;
     if ((p.D & 3) || (!p.out32 && !p.out16) || p.r1_div <= 0 || (p.r2 && p.r2_div <= 0) || p.count <= 0) return hipErrorInvalidValue;
     dim3 grid(p.total, p.B), block(256);
-    const bool fast = p.fast_gelu != 0;
+    const bool fast = p.fast_gelu != 0 || tuning().gelu32 == 1;
     switch (dtype) {
         case F32:
             if (fast) hipLaunchKernelGGL((adapter_apply_kernel<float, true>), grid, block, 0, s, p);

@@ -74,51 +74,68 @@ __device__ __forceinline__ void split8(const float4& x0, const float4& x1, uint4
 // erf-GELU in fp32: nn.GELU() / F.gelu(x.float()) on the reference path.
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
-// erf-GELU with |erf error| <= 1.5e-7 (Abramowitz & Stegun 7.1.26: one v_exp, one v_rcp, a degree-5 Horner) for the
-// 16-bit operand modes, where libm erff would cost more VALU cycles than a K = 768 contraction costs MFMA cycles.
+// erf-GELU with ONE transcendental, for the 16-bit operand modes and the split-precision modes (where libm erff would cost more
+// VALU cycles than a K = 768 contraction costs MFMA cycles):
+//     gelu(x) = max(x, 0) - |x|/2 * erfc(|x| / sqrt 2),        erfc(z) = 2 ^ (z * Q(z)),  Q of degree 7 on z in [0, 6]
+// (Q fitted on [0, 6] to log2(erfc(z)) / z with the error weighted by erfc; beyond it Q keeps falling (Q <= -10, leading
+// coefficient negative), so 2^(z Q) stays below 2^-60 and reaches exactly 0; z is clamped at 16 only so that x = +inf gives
+// +inf instead of inf * 0.  gelu(-inf) and gelu(NaN) are NaN, as in 0.5 * x * (1 + erf(x / sqrt 2)).)
+// erfc is computed directly, so there is no 1 + erf cancellation on the negative side and no reciprocal: 7 FMAs + v_exp_f32.
+// Against an fp64 evaluation on N(0, s) inputs, s = 0.3 / 1 / 3: relative Frobenius error 7.0e-8 / 3.5e-8 / 2.2e-8 — the level of
+// 0.5 * x * (1 + erff(x / sqrt 2)) itself evaluated in fp32 (4.0e-8 / 3.7e-8 / 3.0e-8); the A&S 7.1.26 form of rounds 1-2 (rcp +
+// exp + degree 5) was at 1.3e-7 / 8.7e-8 / 5.2e-8 with 4.5 more issue slots per element.
+#define S3_GELU_Q0 -1.627915263e+00f
+#define S3_GELU_Q1 -9.183272123e-01f
+#define S3_GELU_Q2 -1.488733739e-01f
+#define S3_GELU_Q3 2.905271389e-02f
+#define S3_GELU_Q4 -1.628119033e-03f
+#define S3_GELU_Q5 -9.987915400e-04f
+#define S3_GELU_Q6 3.023426980e-04f
+#define S3_GELU_Q7 -2.878726809e-05f
 __device__ __forceinline__ float gelu_fast(float x) {
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-    float poly = fmaf(1.061405429f, t, -1.453152027f);
-    poly = fmaf(poly, t, 1.421413741f);
-    poly = fmaf(poly, t, -0.284496736f);
-    poly = fmaf(poly, t, 0.254829592f);
-    poly *= t;
-    const float e = __builtin_amdgcn_exp2f(-1.44269504088896340736f * z * z);
-    const float erf_abs = fmaf(-poly, e, 1.0f);
-    const float erf = __builtin_copysignf(erf_abs, x);
-    return 0.5f * x * (1.0f + erf);
+    const float ax = fabsf(x);
+    const float z = fminf(ax * 0.70710678118654752440f, 16.0f);
+    float q = fmaf(S3_GELU_Q7, z, S3_GELU_Q6);
+    q = fmaf(q, z, S3_GELU_Q5);
+    q = fmaf(q, z, S3_GELU_Q4);
+    q = fmaf(q, z, S3_GELU_Q3);
+    q = fmaf(q, z, S3_GELU_Q2);
+    q = fmaf(q, z, S3_GELU_Q1);
+    q = fmaf(q, z, S3_GELU_Q0);
+    const float e = __builtin_amdgcn_exp2f(z * q);             // erfc(z)
+    const float hz = z * 0.70710678118654752440f;               // |x| / 2 inside the fitted range
+    return fmaf(-hz, e, (x + ax) * 0.5f);                       // (x + |x|) / 2 = max(x, 0), exact, NaN-propagating
 }
 
 // The same erf-GELU on a PAIR of values with packed fp32 VALU (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32: one issue slot
-// for two lanes' worth of work; the two transcendentals and the sign transfer stay per element): ~11 issue slots per
-// element instead of 19.  For epilogues and elementwise kernels only — beside MFMAs packed fp32 is an anti-lever
-// (MI355X_MICROARCH.md, per-instruction constants).  Bit-identical to gelu_fast per element (same operations, same order).
+// for two lanes' worth of work; the transcendental, |x| and the clamp stay per element): ~12.5 issue slots per element instead
+// of 19.  For epilogues and elementwise kernels only — beside MFMAs packed fp32 is an anti-lever (MI355X_MICROARCH.md,
+// per-instruction constants).  Bit-identical to gelu_fast per element (same operations, same order).
 __device__ __forceinline__ f32x2 gelu_fast2(f32x2 x) {
     const f32x2 ax = {__builtin_fabsf(x.x), __builtin_fabsf(x.y)};
-    const f32x2 z = ax * 0.70710678118654752440f;
-    const f32x2 d = __builtin_elementwise_fma(z, (f32x2){0.3275911f, 0.3275911f}, (f32x2){1.0f, 1.0f});
-    const f32x2 t = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
-    f32x2 poly = __builtin_elementwise_fma(t, (f32x2){1.061405429f, 1.061405429f}, (f32x2){-1.453152027f, -1.453152027f});
-    poly = __builtin_elementwise_fma(poly, t, (f32x2){1.421413741f, 1.421413741f});
-    poly = __builtin_elementwise_fma(poly, t, (f32x2){-0.284496736f, -0.284496736f});
-    poly = __builtin_elementwise_fma(poly, t, (f32x2){0.254829592f, 0.254829592f});
-    poly = poly * t;
-    const f32x2 zz = (z * -1.44269504088896340736f) * z;
-    const f32x2 e = {__builtin_amdgcn_exp2f(zz.x), __builtin_amdgcn_exp2f(zz.y)};
-    const f32x2 erf_abs = __builtin_elementwise_fma(-poly, e, (f32x2){1.0f, 1.0f});
-    const f32x2 erf = {__builtin_copysignf(erf_abs.x, x.x), __builtin_copysignf(erf_abs.y, x.y)};
-    return (x * 0.5f) * (erf + 1.0f);
+    const f32x2 zu = ax * 0.70710678118654752440f;
+    const f32x2 z = {__builtin_fminf(zu.x, 16.0f), __builtin_fminf(zu.y, 16.0f)};
+    f32x2 q = __builtin_elementwise_fma(z, (f32x2){S3_GELU_Q7, S3_GELU_Q7}, (f32x2){S3_GELU_Q6, S3_GELU_Q6});
+    q = __builtin_elementwise_fma(q, z, (f32x2){S3_GELU_Q5, S3_GELU_Q5});
+    q = __builtin_elementwise_fma(q, z, (f32x2){S3_GELU_Q4, S3_GELU_Q4});
+    q = __builtin_elementwise_fma(q, z, (f32x2){S3_GELU_Q3, S3_GELU_Q3});
+    q = __builtin_elementwise_fma(q, z, (f32x2){S3_GELU_Q2, S3_GELU_Q2});
+    q = __builtin_elementwise_fma(q, z, (f32x2){S3_GELU_Q1, S3_GELU_Q1});
+    q = __builtin_elementwise_fma(q, z, (f32x2){S3_GELU_Q0, S3_GELU_Q0});
+    const f32x2 a = z * q;
+    const f32x2 e = {__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
+    const f32x2 hz = z * 0.70710678118654752440f;
+    return __builtin_elementwise_fma(-hz, e, (x + ax) * 0.5f);
 }
 __device__ __forceinline__ void gelu_fast4(float4& v) {
     const f32x2 a = gelu_fast2((f32x2){v.x, v.y}), b = gelu_fast2((f32x2){v.z, v.w});
     v = make_float4(a.x, a.y, b.x, b.y);
 }
 
-// GELU of the compute mode: libm-exact erf for the fp32 path, the fast erf for the 16-bit operand modes
+// GELU of the compute mode: libm erff for the fp32 path, the one-transcendental form for the 16-bit operand modes
 template <typename T> __device__ __forceinline__ float gelu_mode(float x) { return gelu_fast(x); }
 template <> __device__ __forceinline__ float gelu_mode<float>(float x) { return gelu_erf(x); }
-// four values at once: FAST = the packed 1.5e-7 erf (16-bit operand modes and the split-precision mode), else libm erff
+// four values at once: FAST = the packed one-transcendental form (16-bit operand modes, split-precision modes), else libm erff
 template <bool FAST> __device__ __forceinline__ void gelu4(float& a, float& b, float& c, float& d) {
     if constexpr (FAST) {
         const f32x2 p = gelu_fast2((f32x2){a, b}), q = gelu_fast2((f32x2){c, d});
@@ -138,19 +155,62 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
+// Wave-wide reductions with the result in every lane: the xor butterfly `v = v (op) __shfl_xor(v, o)`, o = 32, 16, 8, 4, 2, 1 —
+// same pairing and same order, and (op) commutative, so bit-identical to it — WITHOUT the LDS: __shfl_xor lowers to
+// ds_bpermute_b32 + s_waitcnt lgkmcnt(0), six dependent LDS round trips per reduction (two reductions per LayerNorm row;
+// 12 on the critical path of every frame of the layer_norm-mode conv0).  xor_pair<O>(u, a, b) returns {own, partner} of the
+// lane pair (l, l ^ O) in an order that is the same for both lanes of the pair:
+//   O = 32 / 16: v_permlane32_swap / v_permlane16_swap of a register with its copy leave {lower's, lower's} and {upper's, upper's};
+//   O = 8: DPP row_ror:8;  O = 4: row_shl:4 on banks 0 / 2 + row_shr:4 on banks 1 / 3;  O = 2 / 1: quad_perm.
+template <int O> __device__ __forceinline__ void xor_pair(unsigned u, unsigned& a, unsigned& b) {
+    if constexpr (O == 32) {
+        const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+        a = r[0]; b = r[1];
+    } else if constexpr (O == 16) {
+        const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+        a = r[0]; b = r[1];
+    } else if constexpr (O == 8) {
+        a = u; b = (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0x128, 0xf, 0xf, false);           // row_ror:8
+    } else if constexpr (O == 4) {
+        const int t = __builtin_amdgcn_update_dpp(0, (int)u, 0x104, 0xf, 0x5, false);                  // row_shl:4 -> lanes of banks 0, 2
+        a = u; b = (unsigned)__builtin_amdgcn_update_dpp(t, (int)u, 0x114, 0xf, 0xa, false);           // row_shr:4 -> lanes of banks 1, 3
+    } else if constexpr (O == 2) {
+        a = u; b = (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0x4E, 0xf, 0xf, false);            // quad_perm [2,3,0,1]
+    } else {
+        a = u; b = (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0xB1, 0xf, 0xf, false);            // quad_perm [1,0,3,2]
+    }
+}
+template <int O> __device__ __forceinline__ float xor_sum_f(float v) {
+    unsigned a, b;
+    xor_pair<O>(__float_as_uint(v), a, b);
+    return __uint_as_float(a) + __uint_as_float(b);
+}
+template <int O> __device__ __forceinline__ float xor_max_f(float v) {
+    unsigned a, b;
+    xor_pair<O>(__float_as_uint(v), a, b);
+    return fmaxf(__uint_as_float(a), __uint_as_float(b));
+}
+template <int O> __device__ __forceinline__ double xor_sum_d(double v) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    unsigned alo, blo, ahi, bhi;
+    xor_pair<O>((unsigned)u, alo, blo);
+    xor_pair<O>((unsigned)(u >> 32), ahi, bhi);
+    return __longlong_as_double((long long)(((unsigned long long)ahi << 32) | alo)) +
+           __longlong_as_double((long long)(((unsigned long long)bhi << 32) | blo));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    v = xor_sum_f<32>(v); v = xor_sum_f<16>(v); v = xor_sum_f<8>(v);
+    v = xor_sum_f<4>(v); v = xor_sum_f<2>(v); v = xor_sum_f<1>(v);
     return v;
 }
 __device__ __forceinline__ double wave_sum_d(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    v = xor_sum_d<32>(v); v = xor_sum_d<16>(v); v = xor_sum_d<8>(v);
+    v = xor_sum_d<4>(v); v = xor_sum_d<2>(v); v = xor_sum_d<1>(v);
     return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    v = xor_max_f<32>(v); v = xor_max_f<16>(v); v = xor_max_f<8>(v);
+    v = xor_max_f<4>(v); v = xor_max_f<2>(v); v = xor_max_f<1>(v);
     return v;
 }
 

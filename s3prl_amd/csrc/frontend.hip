@@ -142,9 +142,9 @@ constexpr int C0_FT = 64;  // frames per block
 // CS = waves that share one frame, each owning a contiguous C / CS slice of the channels (GroupNorm mode only: no
 // reduction across channels).  CS = 2 for C = 512 halves the per-lane weight registers (149 -> 81 VGPRs, 3 -> 5-6 waves
 // per SIMD), which is what lets the GELU arithmetic of one wave overlap the 1 KiB row stores of another.
-// FAST: packed fp32 arithmetic for the taps (v_pk_fma_f32 on channel pairs) and the packed 1.5e-7 erf-GELU — the 16-bit
-// operand modes and the split-precision mode (this kernel is VALU-bound there: 40 FMAs + ~80 GELU slots per 4 outputs);
-// the exact fp32 mode keeps scalar FMAs in tap order and libm erff.
+// FAST: packed fp32 arithmetic for the taps (v_pk_fma_f32 on channel pairs) and the packed one-transcendental GELU (common.h) — the
+// 16-bit operand modes and the split-precision modes (this kernel is VALU-bound there: 40 FMAs + ~50 GELU slots per 4
+// outputs), and the fp32 mode by default (tuning key gelu32 = 0: scalar FMAs in the same tap order and libm erff).
 template <typename T, int NG, int K0, int CS = 1, bool FAST = false>
 __global__ __launch_bounds__(256) void conv0_kernel(Conv0Params p) {
     typedef typename Cvt<T>::store_t store_t;
@@ -333,7 +333,7 @@ hipError_t launch_conv0(int dtype, const Conv0Params& p, hipStream_t s) {
     // the kernel is specialised for the first layer every released checkpoint has: k = 10, stride <= 8, C <= 1024
     if (p.k0 != 10 || p.s0 > 8 || p.s0 < 1 || p.C > 1024 || (p.C & 3)) return hipErrorInvalidValue;
     switch (dtype) {
-        case F32: return p.fast ? conv0_dispatch<float, true>(p, s) : conv0_dispatch<float, false>(p, s);
+        case F32: return (p.fast || tuning().gelu32 == 1) ? conv0_dispatch<float, true>(p, s) : conv0_dispatch<float, false>(p, s);
         case BF16: return conv0_dispatch<bf16_tag, true>(p, s);
         case F16: return conv0_dispatch<f16_tag, true>(p, s);
     }

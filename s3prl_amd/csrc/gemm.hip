@@ -248,7 +248,11 @@ __global__ __launch_bounds__(256, ROWB == 128 ? 2 : (GLDS ? 5 : 3)) void gemm_ke
                 if (m < p.M && n_ok) {
                     v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
                     if (p.act) {
-                        v.x = gelu_mode<T>(v.x); v.y = gelu_mode<T>(v.y); v.z = gelu_mode<T>(v.z); v.w = gelu_mode<T>(v.w);
+                        if (!std::is_same<T, float>::value || p.act == 2) {
+                            gelu_fast4(v);
+                        } else {
+                            v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
+                        }
                     }
                     const long o = ob + (long)m * p.ldo + n;
                     if (p.residual) {
@@ -279,7 +283,7 @@ __global__ __launch_bounds__(256, ROWB == 128 ? 2 : (GLDS ? 5 : 3)) void gemm_ke
                 const int m = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (m >= p.M) continue;
                 float v = acc[i][j][r] + bias;
-                if (p.act) v = gelu_mode<T>(v);
+                if (p.act) v = (p.act == 2) ? gelu_fast(v) : gelu_mode<T>(v);
                 const long o = ob + (long)m * p.ldo + n;
                 if (p.residual) v += p.residual[o];
                 if (m >= limit) v = 0.f;
@@ -328,6 +332,7 @@ hipError_t launch_gemm(int dtype, const GemmParams& p0, hipStream_t stream) {
     GemmParams p = p0;
     if (p.variant < 0) p.variant = tuning().gemm_variant;  // default 3: 64-byte stages + LDS-DMA (register staging for a ragged K)
     if (p.M <= 0 || p.N <= 0 || p.batches <= 0) return hipSuccess;
+    if (dtype == F32 && p.act == 1 && tuning().gelu32 == 1) p.act = 2;  // fp32 products, the one-transcendental GELU
     if (p.wsplit) {
         if (dtype == F32) return hipErrorInvalidValue;
         if (!p.ldw) p.ldw = 2L * p.K;

@@ -23,10 +23,10 @@
 //     residual and the padded-frame zeroing run on row-contiguous float4s and every global access is a full
 //     16-byte (fp32) / 8-byte (16-bit) vector; specialised at compile time on the four flag combinations of the path;
 //     v_cvt_pk_bf16_f32 / v_cvt_f16_f32 for the 16-bit stores.
-//   * GELU in the 16-bit modes uses a 1.5e-7-accurate erf (Abramowitz-Stegun 7.1.26: one v_exp + one v_rcp + a
-//     degree-5 Horner, 19 VALU) instead of libm's erff (38 VALU with a divergent branch): at K = 768 the erff
-//     epilogue costs about as many VALU cycles as the whole K loop costs MFMA cycles.  The error is 3 orders below
-//     the operand rounding of these modes; the fp32 mode (gemm.hip) keeps erff.
+//   * GELU in the 16-bit modes is the one-transcendental form of common.h (gelu_fast: one v_exp_f32 + a degree-7
+//     Horner, packed on pairs) instead of libm's erff (38 VALU with a divergent branch): at K = 768 the erff
+//     epilogue costs about as many VALU cycles as the whole K loop costs MFMA cycles.  Its error is at the fp32
+//     rounding level, and the fp32 mode uses it too (libm erff under the tuning key gelu32 = 0).
 // Measured: profiles/r02_gemm16_variants.md, r02_pmc_gemm16.md (700-1000 TF on the shapes of the path, 1.15 PF at 8192^3:
 // MFMA-busy 0.61 at a power-limited ~1.55 GHz; 18 % more on zero-filled operands).
 // Requirements (checked by the launcher, which otherwise falls back to gemm.hip): K a multiple of 64, N / ldo /

@@ -17,8 +17,8 @@
 //   * tile / pipeline as gemm16.hip mode 1: 256x256 (or 192x256) tile, 8 waves, one workgroup per CU, two LDS stages of
 //     128 bytes per row (= 32 k here), LDS-DMA from inline asm interleaved with the MFMA steps, source-side XOR
 //     swizzle; 48 MFMAs per wave between barriers.
-//   * epilogue: wave-private LDS transpose, float4 stores, fp32 residual; GELU with the 1.5e-7-accurate erf of the
-//     16-bit modes (two orders below this mode's own 1e-5; libm erff costs twice the VALU).
+//   * epilogue: wave-private LDS transpose, float4 stores, fp32 residual; GELU in the one-transcendental form of the
+//     16-bit modes (common.h gelu_fast: fp32 rounding level; libm erff costs three times the VALU).
 // Requirements (else the launcher falls back to the exact kernel): K % 32 == 0, N / ldo / o_bs % 4 == 0, 16-byte
 // alignment, M and N >= 128, the pair-packed weights present.
 #include <type_traits>

@@ -271,8 +271,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(GemmParams p) {
                 if (m < p.M && n_ok) {
                     v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
                     if (p.act) {
-                        if constexpr (X3) {
-                            gelu_fast4(v);  // the packed 1.5e-7 erf: two orders below this mode's own 1e-5
+                        if (X3 || p.act == 2) {
+                            gelu_fast4(v);  // the packed one-transcendental form (act 2: asked for in fp32 too)
                         } else {
                             v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
                         }

@@ -32,6 +32,7 @@ struct Tuning {
     int gemm_x3_tile = 1;  // gemmt.hip, S3ENC_F32X3: 0 off, 1 = only the shapes with few tiles, 2..5 = force a height
     int gemm16_big = 3;    // gemm16.hip: 0 off, 3 = choose by shape, 1 / 2 / 4 / 5 / 6 = force one configuration
     int attn_lds_pad = 0;  // 16-bit attention occupancy probe
+    int gelu32 = 1;        // S3ENC_F32: 1 = the one-transcendental GELU of every mode (common.h gelu_fast; fp32 rounding level), 0 = libm erff
     int x3_pack_cache = 0; // s3enc_op_gemm(S3ENC_F32X3): keep the packed image of the last weight (micro-benchmarks)
 };
 extern Tuning g_tuning;
@@ -108,7 +109,7 @@ struct Conv0Params {
     int C, k0, s0;
     long L0;
     void* out;            // (B, L0, C) compute dtype
-    int fast = 0;         // fp32 output with the packed 1.5e-7 erf-GELU (the split-precision mode S3ENC_F32X3)
+    int fast = 0;         // fp32 output with the packed one-transcendental GELU (the split-precision modes)
 };
 hipError_t launch_conv0(int dtype, const Conv0Params& p, hipStream_t s);
 
@@ -131,7 +132,8 @@ struct LnGate {
     float* gate = nullptr;      // (B, H, T) or null: no gate
     int T = 0, H = 0;
 };
-// act: 0 none, 1 erf-GELU of the mode (fp32: libm erff; 16-bit: the 1.5e-7 erf), 2 the 1.5e-7 erf regardless of dtype
+// act: 0 none, 1 erf-GELU of the mode (16-bit: common.h gelu_fast; fp32: the same unless tuning gelu32 = 0 -> libm erff),
+//      2 gelu_fast regardless of dtype and tuning
 hipError_t launch_layernorm(int dtype, const float* x, const float* gamma, const float* beta, long rows, int C, int act,
                             float* out32, void* out16, hipStream_t s, const LnAcc& fa = LnAcc(), const LnGate& gt = LnGate());
 // a state produced by a non-LayerNorm kernel: its 16-bit copy (out16, dtype BF16 / F16) and / or its Featurizer term
@@ -206,7 +208,7 @@ struct AdapterApplyParams {
     const int* zero_from;   // optional [B]: frames >= zero_from[b] are written as zero (the next encoder's index_put)
     float* out32;
     void* out16;
-    int fast_gelu;          // fp32 instantiation only: the 1.5e-7 erf (S3ENC_F32X3); the 16-bit ones always use it
+    int fast_gelu;          // fp32 instantiation only: gelu_fast (S3ENC_F32X3); the 16-bit ones always use it
 };
 hipError_t launch_adapter_apply(int dtype, const AdapterApplyParams& p, hipStream_t s);
 // state of a block -> (B, rows_out, D) slot: out[b][t] = x[b][t / factor]  (repeat_interleave + cut, expert.py:26-27,93-101)

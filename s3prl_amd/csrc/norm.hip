@@ -248,6 +248,7 @@ hipError_t launch_layernorm(int dtype, const float* x, const float* gamma, const
     if (rows <= 0) return hipSuccess;
     if ((C & 3) || C > 2048) return hipErrorInvalidValue;
     if (gt.gate && (gt.H * 64 != C || gt.T <= 0 || act)) return hipErrorInvalidValue;
+    if (dtype == F32 && act == 1 && tuning().gelu32 == 1) act = 2;
     switch (dtype) {
         case F32: return ln_dispatch<float>(x, gamma, beta, rows, C, act, out32, out16, fa, gt, s);
         case BF16: return ln_dispatch<bf16_tag>(x, gamma, beta, rows, C, act, out32, out16, fa, gt, s);

@@ -93,11 +93,11 @@ def test_tuning_keys_are_validated_process_wide_and_per_handle():
     assert lib.s3enc_set_tuning(b"no_such_key", 0) != 0 and b"unknown key" in lib.s3enc_last_error()
     assert lib.s3enc_set_tuning(None, 0) != 0
     assert lib.s3enc_set_handle_tuning(None, b"gemm32_big", 1) != 0 and b"null handle" in lib.s3enc_last_error()
-    for key in (b"gemm_variant", b"gemm_x3_tile", b"gemm16_big", b"attn_lds_pad", b"gemm_lds_pad", b"x3_pack_cache"):
+    for key in (b"gemm_variant", b"gemm_x3_tile", b"gemm16_big", b"attn_lds_pad", b"gemm_lds_pad", b"x3_pack_cache", b"gelu32"):
         assert lib.s3enc_set_tuning(key, 0) == 0, key
     # restore the defaults other tests rely on
     assert lib.s3enc_set_tuning(b"gemm_variant", 3) == 0 and lib.s3enc_set_tuning(b"gemm_x3_tile", 1) == 0
-    assert lib.s3enc_set_tuning(b"gemm16_big", 3) == 0
+    assert lib.s3enc_set_tuning(b"gemm16_big", 3) == 0 and lib.s3enc_set_tuning(b"gelu32", 1) == 0
 
 
 def test_comm_entry_points_fail_cleanly_without_a_communicator():

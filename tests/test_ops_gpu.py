@@ -530,3 +530,38 @@ def test_gemm32_big_tile_is_bit_identical_to_the_default_kernel(shape):
     assert torch.isfinite(outs[0]).all()
     for mode, out in enumerate(outs[1:], start=1):
         assert torch.equal(outs[0], out), f"gemm32_big = {mode} differs from the 128x128 kernel"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scale", [0.3, 1.0, 3.0, 12.0])
+def test_one_transcendental_gelu_is_at_fp32_rounding_level(scale):
+    """common.h gelu_fast: gelu(x) = max(x, 0) - |x|/2 * 2^(z Q(z)), z = |x| / sqrt 2 (one v_exp_f32, no reciprocal) — the GELU
+    of every mode (the fp32 mode falls back to libm erff under the tuning key gelu32 = 0).  Through an identity
+    product (W = I: every fp32 product and sum is exact) the GEMM epilogue returns gelu(A + bias): against torch's fp64
+    erf-GELU (nn.GELU, wav2vec2_model.py:2896) it must sit at the level of the libm form evaluated in fp32 (~4e-8)."""
+    torch = _torch()
+    from s3prl_amd import _lib
+
+    lib = _lib.load()
+    M, N = 4096, 128
+    g = torch.Generator(device="cuda").manual_seed(int(scale * 10))
+    A = torch.randn(M, N, device="cuda", generator=g) * scale
+    A[0, :8] = torch.tensor([0.0, -0.0, 1e-30, -1e-30, 40.0, -40.0, 1e30, -1e30], device="cuda")
+    W = torch.eye(N, device="cuda")
+    ref = torch.nn.functional.gelu(A.double())
+    errs = {}
+    try:
+        for key in (0, 1):
+            _lib.check(lib.s3enc_set_tuning(b"gelu32", key))
+            out = torch.full((M, N), float("nan"), device="cuda")
+            _lib.check(lib.s3enc_op_gemm(0, _ptr(A), N, M * N, _ptr(W), None, M, N, N, 1, 1, None, None, _ptr(out), None, N, M * N, None))
+            torch.cuda.synchronize()
+            assert torch.isfinite(out).all()
+            errs[key] = ((out.double() - ref).norm() / ref.norm()).item()
+            # exact at the ends: 0 -> 0, large positive -> x, large negative -> -0 (no NaN from inf * 0 or 1 + erf cancellation)
+            assert out[0, 0].item() == 0.0 and out[0, 1].item() == 0.0
+            assert out[0, 4].item() == 40.0 and out[0, 6].item() == A[0, 6].item() and abs(out[0, 5].item()) < 1e-30 and abs(out[0, 7].item()) < 1e-6
+    finally:
+        _lib.check(lib.s3enc_set_tuning(b"gelu32", 1))
+    assert errs[0] < 1.0e-7, errs            # libm erff
+    assert errs[1] < 1.5e-7, errs            # the one-transcendental form: the same level

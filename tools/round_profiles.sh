@@ -4,6 +4,7 @@
 #   rocprofv3 kernel-trace summary; the operand modes of the headline workload; the micro labs; the parity table.
 # Raw rocprof output stays on the box (only the summaries are merged back: gpurun_out is capped at 64 MiB).
 # usage: tools/round_profiles.sh r03        (most important artefacts first: a cut-off run still leaves them)
+#        PROFILE_ONLY="fp32 bf16" tools/round_profiles.sh r03   (PMC + rocprof only for the named configurations, bench lines for all)
 set -u
 tag=${1:-r03}
 export TMPDIR=/tmp
@@ -15,6 +16,11 @@ Q="--no-cpu-baseline --no-other-modes"
 profile_cfg() {
   local name=$1 sub=$2 model=$3 dtype=$4 batch=$5 secs=$6 extra=$7 steps=$8
   local args="--model $model --dtype $dtype --batch $batch --secs $secs $extra"
+  if [ -n "${PROFILE_ONLY:-}" ] && ! echo " $PROFILE_ONLY " | grep -q " $name "; then
+    # bench line only: its roofline.traffic comes from the record an earlier full run left in profiles/traffic.json
+    python bench.py $args --steps $steps --warmup 2 $Q > $out/bench_$name.json 2> $out/bench_$name.err
+    return
+  fi
   PMC_GROUPS="sq1 sq2 tcc fetch write" tools/pmc.sh ${tag}_$name python bench.py $args --steps 2 --warmup 1 $Q --no-parity > /dev/null 2>&1
   python tools/pmc_to_traffic.py gpurun_out/pmc_${tag}_$name $model $dtype $batch $secs profiles/traffic.json $sub > $out/traffic_$name.json 2>/dev/null
   cp gpurun_out/pmc_${tag}_$name.md $out/pmc_$name.md 2>/dev/null
