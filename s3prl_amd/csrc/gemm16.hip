@@ -398,7 +398,9 @@ bool gemm16_big_eligible(int dtype, const GemmParams& p) {
     const uintptr_t al = (uintptr_t)p.A | (uintptr_t)p.W | (uintptr_t)p.out32 | (uintptr_t)p.residual | (uintptr_t)p.bias;
     if (al & 15) return false;
     if (((uintptr_t)p.out16) & 7) return false;
-    return p.M >= 128 && p.N >= 128;
+    // no lower bound on M: loads clamp and stores mask ragged rows, and a batch of few frames must take the kernel (and with it
+    // the k grouping per MFMA, i.e. the rounding) its rows would take inside a large batch
+    return p.N >= 128;
 }
 
 hipError_t launch_gemm16_big(int dtype, const GemmParams& p, hipStream_t stream) {

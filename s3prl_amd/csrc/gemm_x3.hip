@@ -226,7 +226,7 @@ bool gemm_x3_eligible(const GemmParams& p) {
     if (((p.lda * 4) & 15) || ((p.a_bs * 4) & 15)) return false;
     const uintptr_t al = (uintptr_t)p.A | (uintptr_t)p.W_x3 | (uintptr_t)p.out32 | (uintptr_t)p.residual | (uintptr_t)p.bias;
     if (al & 15) return false;
-    return p.M >= 128 && p.N >= 128;
+    return p.N >= 128;  // any M (ragged rows are clamped / masked): a row's arithmetic must not depend on the batch it sits in
 }
 
 hipError_t launch_gemm_x3(const GemmParams& p, hipStream_t stream) {

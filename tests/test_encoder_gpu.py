@@ -284,7 +284,30 @@ def test_long_single_utterance_and_one_frame_neighbour(name):
     enc.close()
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
+@pytest.mark.parametrize("dtype", ["fp32", "fp32x3", "fp16x2", "bf16"])
+def test_one_utterance_alone_equals_its_rows_in_a_batch_bit_for_bit(dtype):
+    """A row's rounding must not depend on the batch it sits in (shards padded to the global n_max reproduce the
+    full batch): one 2 s utterance alone is M = 99 rows — below every large tile's row count — and the same utterance among five
+    is M = 495; the GEMM dispatch (tile heights, the two-term fp16x2 kernel that stages both weight terms, the 128x128 fallback)
+    must give it the same bits both ways, in every operand mode."""
+    import torch
+    from s3prl_amd.synth import named_config, synth_weights
+
+    cfg = named_config("hubert_base")
+    enc = _encoder(cfg, synth_weights(cfg, 0), dtype=dtype)
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    wavs = [torch.randn(n, device="cuda", generator=gen) for n in (32000, 32000, 20000, 32000, 9000)]
+    full = enc.forward(wavs).clone()
+    torch.cuda.synchronize()
+    assert torch.isfinite(full.float()).all()
+    for i in (0, 2, 4):
+        alone = enc.forward([wavs[i]], n_max=32000)
+        torch.cuda.synchronize()
+        assert torch.equal(alone[:, 0], full[:, i]), f"utterance {i} differs between B = 1 and B = 5 ({dtype})"
+    enc.close()
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16", "fp16x2"])
 def test_race_screen_repeated_runs_are_bit_identical(dtype):
     """The GEMM kernels overlap LDS-DMA (issued from inline asm, hand-counted vmcnt) with the MFMA loop; a missing wait
     or barrier would show as run-to-run differences.  HuBERT-base shapes (every GEMM mode of the path: 128x128 fp32,
