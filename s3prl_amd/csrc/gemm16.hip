@@ -12,6 +12,9 @@
 //       mode 1  256x256 (or 192x256, whichever leaves fewer idle CU-rounds) tile, 2 stages of 64 k, one workgroup per CU
 //               (128 FLOP per staged byte) — the default for every shape since the 16-bit epilogues store 16 bytes per
 //               lane (round 2: q|k|v 64 vs 72 us, fc1 99 vs 104 us against mode 4);
+//       mode 7  mode 1's tiles walked by ONE persistent workgroup per CU (the default since late round 3): the first K step of
+//               the next tile is issued before the current tile's epilogue, bit-identical to mode 1 (tests), q|k|v 70.9 -> 66.4 us,
+//               1 % on the other shapes (profiles/r03_gemm16_loop_probe.md);
 //       mode 4  128x256 tile, ring of 3 stages of 32 k with two K-steps in flight, two workgroups per CU that hide
 //               each other's barriers and epilogues — kept as a tuning option (`gemm16_big` = 4).
 //     (Round 2's phase-pipelined variant, gemm16p.hip — staggered wave rows, region-granular DMA ring — measured equal or
@@ -67,7 +70,11 @@ template <> struct Mma16<f16_tag> {
 // register budget is capped for (2 = one workgroup per CU, 4 = two).
 // WN: waves along N (4: 8-wave workgroup, 256 columns; 2: 4-wave workgroup, 128 columns — two such workgroups per CU
 // put ONE wave of each on every SIMD, so their barriers and epilogues interleave).
-template <typename T, int WTM, int ROWB, int NST, int WPE, int WN>
+// PERSIST: one workgroup per CU walks ITS tiles (the XCD's contiguous range, strided by the XCD's workgroups) and issues the
+// first K step of the next tile by LDS-DMA before it starts the epilogue of the current one — the per-tile prologue (arguments,
+// addresses, a first stage with nothing to overlap it: ~2.5 us of a 24 us q|k|v tile, profiles/r03_gemm16_loop_probe.md) runs
+// under the epilogue, whose LDS staging moves out of stage 0's way (behind it).
+template <typename T, int WTM, int ROWB, int NST, int WPE, int WN, bool PERSIST = false>
 __global__ __launch_bounds__(128 * WN, WPE) void gemm16_big_kernel(GemmParams p) {
     constexpr int NTHR = 128 * WN;  // 2 waves along M x WN along N
     constexpr int BM = 2 * WTM, BN = 64 * WN;
@@ -91,22 +98,38 @@ __global__ __launch_bounds__(128 * WN, WPE) void gemm16_big_kernel(GemmParams p)
     // XCD-aware tile order (see gemm.hip): every XCD gets a contiguous range of (batch, m-tile, n-tile), n fastest
     const int n_tiles = (p.N + BN - 1) / BN;
     const int m_tiles = (p.M + BM - 1) / BM;
-    int tile;
+    int tile, tile_end, tile_step;  // this workgroup's tiles: tile, tile + tile_step, ... < tile_end
     {
-        const int nwg = gridDim.x, wg = blockIdx.x;
-        const int q8 = nwg >> 3, r8 = nwg & 7, xcd = wg & 7, loc = wg >> 3;
-        tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
+        const int nwg = gridDim.x, wg = blockIdx.x, xcd = wg & 7, loc = wg >> 3;
+        if constexpr (PERSIST) {
+            const int total = n_tiles * m_tiles * p.batches;
+            const int q8 = total >> 3, r8 = total & 7;
+            const int start = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+            tile_end = start + q8 + (xcd < r8 ? 1 : 0);
+            tile_step = (nwg >> 3) + (xcd < (nwg & 7) ? 1 : 0);
+            tile = start + loc;
+            if (tile >= tile_end) return;
+        } else {
+            const int q8 = nwg >> 3, r8 = nwg & 7;
+            tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
+            tile_end = tile + 1;
+            tile_step = 1;
+        }
     }
-    const int tn = tile % n_tiles;
-    const int tmb = tile / n_tiles;
-    const int tm = tmb % m_tiles, b = tmb / m_tiles;
-    const int m0 = tm * BM, n0 = tn * BN;
+    int m0, n0, b;  // the tile being multiplied / written
+    auto coords = [&](int t, int& cm0, int& cn0, int& cb) {
+        const int tn = t % n_tiles;
+        const int tmb = t / n_tiles;
+        cm0 = (tmb % m_tiles) * BM;
+        cn0 = tn * BN;
+        cb = tmb / m_tiles;
+    };
+    coords(tile, m0, n0, b);
 
     const long lda_b = p.lda * 2;
     const long kbytes = (long)p.K * 2;                      // bytes of A's K extent
     const long wk = p.wsplit ? 2 * kbytes : kbytes;        // bytes of the contraction: [hi | lo] weights run A twice
     const long ldw_b = p.ldw ? p.ldw * 2 : wk;              // W row stride
-    const char* Ab = (const char*)p.A + (long)b * p.a_bs * 2;
     const char* Wb = (const char*)p.W;
     const int nk = (int)(wk / ROWB);
 
@@ -117,18 +140,22 @@ __global__ __launch_bounds__(128 * WN, WPE) void gemm16_big_kernel(GemmParams p)
     const int ls = ps ^ ((lr >> SSH) & SMASK);
     const char* a_ptr[NLA];
     const char* w_ptr[NLB];
+    auto set_ptrs = [&](int pm0, int pn0, int pb) {
+        const char* Ab = (const char*)p.A + (long)pb * p.a_bs * 2;
 #pragma unroll
-    for (int i = 0; i < NLA; ++i) {
-        int ra = ((p.variant & 8) ? 0 : m0) + lr + RPP * i;  // variant bit 3: every tile loads tile 0 (timing probe only)
-        ra = ra < p.M ? ra : p.M - 1;
-        a_ptr[i] = Ab + (long)ra * lda_b + ls * 16;
-    }
+        for (int i = 0; i < NLA; ++i) {
+            int ra = ((p.variant & 8) ? 0 : pm0) + lr + RPP * i;  // variant bit 3: every tile loads tile 0 (timing probe only)
+            ra = ra < p.M ? ra : p.M - 1;
+            a_ptr[i] = Ab + (long)ra * lda_b + ls * 16;
+        }
 #pragma unroll
-    for (int i = 0; i < NLB; ++i) {
-        int rw = ((p.variant & 8) ? 0 : n0) + lr + RPP * i;
-        rw = rw < p.N ? rw : p.N - 1;
-        w_ptr[i] = Wb + (long)rw * ldw_b + ls * 16;
-    }
+        for (int i = 0; i < NLB; ++i) {
+            int rw = ((p.variant & 8) ? 0 : pn0) + lr + RPP * i;
+            rw = rw < p.N ? rw : p.N - 1;
+            w_ptr[i] = Wb + (long)rw * ldw_b + ls * 16;
+        }
+    };
+    set_ptrs(m0, n0, b);
     // LDS-DMA issued from inline asm: hipcc does not count it, so it inserts no vmcnt(0) in front of the fragment
     // ds_reads of the stage being multiplied (with the builtin it does — the DMA is a pending LDS write it cannot
     // disambiguate — which serialises load and compute); completion is waited for by hand before the stage barrier.
@@ -173,12 +200,15 @@ __global__ __launch_bounds__(128 * WN, WPE) void gemm16_big_kernel(GemmParams p)
     const int w_row0 = A_BYTES + (wc * 64 + l31) * ROWB;
 
     f32x16 acc[MI][2];
+    auto zero_acc = [&]() {
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    };
+    zero_acc();
 
     // multiply stage `stage`; when `pf`, also issue the DMA pieces of K-step kt_pf into stage_pf, spread over the
     // NQ fragment steps (right after each step's ds_reads): an LDS-DMA instruction costs 60-180 issue cycles
@@ -208,7 +238,9 @@ __global__ __launch_bounds__(128 * WN, WPE) void gemm16_big_kernel(GemmParams p)
         }
     };
 
-    if (S3_GPROBE(p, 64)) {
+    if constexpr (PERSIST) {
+        static_assert(!PERSIST || NST == 2, "the persistent tile loop is written for the 2-stage pipeline");
+    } else if (S3_GPROBE(p, 64)) {
     } else if constexpr (NST == 2) {
         issue(0, 0);
         barrier_all();  // stage 0 is visible to every wave
@@ -235,7 +267,7 @@ __global__ __launch_bounds__(128 * WN, WPE) void gemm16_big_kernel(GemmParams p)
     }
 
 #if defined(S3_GEMM_PROBE) && defined(__HIP_DEVICE_COMPILE__)
-    if (S3_GPROBE(p, 32)) {
+    if (!PERSIST && S3_GPROBE(p, 32)) {
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -243,11 +275,12 @@ __global__ __launch_bounds__(128 * WN, WPE) void gemm16_big_kernel(GemmParams p)
         return;
     }
 #endif
+    auto run_epilogue = [&]() {  // of tile (m0, n0, b)
     // ---- epilogue through a wave-private LDS transpose: 32 x 64 fp32 per step ----
     // Specialised at compile time on (GELU, residual, fp32 out, 16-bit out) for the four combinations the encoder uses
     // — the generic form tests five uniform flags per 4-row pass (168 branches per tile) — with a generic fallback.
     typedef typename Cvt<T>::store_t store_t;
-    float* stg = (float*)(smem + wave * 8192);
+    float* stg = (float*)(smem + (PERSIST ? STAGE_BYTES : 0) + wave * 8192);
     const int limit = p.row_limit ? p.row_limit[b] : p.M;
     const long ob = (long)b * p.o_bs;
     const int c4 = (lane & 15) * 4;
@@ -351,18 +384,51 @@ __global__ __launch_bounds__(128 * WN, WPE) void gemm16_big_kernel(GemmParams p)
     else if (!a && r && w32 && !w16) epilogue(TT{}, FF{}, TT{}, TT{}, FF{});          // out_proj, fc2
     else if (a && !r && w32 && !w16) epilogue(TT{}, TT{}, FF{}, TT{}, FF{});          // last conv (feeds the fp32 LayerNorm)
     else epilogue(FF{}, FF{}, FF{}, FF{}, FF{});
+    };
+    if constexpr (!PERSIST) {
+        run_epilogue();
+    } else {
+        issue(0, 0);
+        for (;;) {
+            barrier_all();  // stage 0 of this tile has landed; every wave is done with the previous tile's epilogue staging
+            for (int kt = 0; kt < nk; ++kt) {
+                compute(kt & 1, kt + 1 < nk, kt + 1, (kt + 1) & 1);
+                barrier_all();
+            }
+            const int next = tile + tile_step;
+            const bool has_next = next < tile_end;  // workgroup-uniform
+            if (has_next) {  // the next tile's first K step goes out before this tile's epilogue: both stage buffers are free
+                int nm0, nn0, nb;
+                coords(next, nm0, nn0, nb);
+                set_ptrs(nm0, nn0, nb);
+                issue(0, 0);
+            }
+            run_epilogue();
+            if (!has_next) break;
+            tile = next;
+            coords(tile, m0, n0, b);
+            zero_acc();
+        }
+    }
 }
 
-template <typename T, int WTM, int ROWB, int NST, int WPE, int WN = 4>
+template <typename T, int WTM, int ROWB, int NST, int WPE, int WN = 4, bool PERSIST = false>
 hipError_t big_go(const GemmParams& p, hipStream_t stream) {
     constexpr int BM = 2 * WTM, BN = 64 * WN, NTHR = 128 * WN;
-    constexpr int lds = NST * (BM + BN) * ROWB;
-    static_assert(lds >= 2 * WN * 8192, "epilogue staging must fit");
+    constexpr int stage = (BM + BN) * ROWB, staging = 2 * WN * 8192;
+    // PERSIST: the epilogue's staging sits behind stage 0, which the next tile's first K step is landing in meanwhile
+    constexpr int lds = PERSIST ? (NST * stage > stage + staging ? NST * stage : stage + staging) : NST * stage;
+    static_assert(lds >= staging, "epilogue staging must fit");
     static_assert(lds * (WPE * 4 * 64 / NTHR) <= 160 * 1024, "workgroups per CU x LDS");
-    auto kern = gemm16_big_kernel<T, WTM, ROWB, NST, WPE, WN>;
-    hipError_t e = ensure_dynamic_lds<gemm16_big_kernel<T, WTM, ROWB, NST, WPE, WN>>(lds);
+    auto kern = gemm16_big_kernel<T, WTM, ROWB, NST, WPE, WN, PERSIST>;
+    hipError_t e = ensure_dynamic_lds<gemm16_big_kernel<T, WTM, ROWB, NST, WPE, WN, PERSIST>>(lds);
     if (e != hipSuccess) return e;
-    dim3 grid(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.batches);
+    long tiles = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.batches;
+    if (PERSIST) {
+        const int cus = device_cus();
+        if (tiles > cus) tiles = cus;
+    }
+    dim3 grid((unsigned)tiles);
     hipLaunchKernelGGL(kern, grid, dim3(NTHR), lds, stream, p);
     return hipGetLastError();
 }
@@ -378,6 +444,12 @@ hipError_t big_mode(int mode, const GemmParams& p, hipStream_t stream) {
             const long c256 = ((t256 + 255) / 256) * 256, c192 = ((t192 + 255) / 256) * 192;
             // (the smaller tile is ~8 % less efficient per row: conv1 890 vs 840 TF at equal CU utilisation)
             return c192 * 11 < c256 * 10 ? big_go<T, 96, 128, 2, 2>(p, stream) : big_go<T, 128, 128, 2, 2>(p, stream);
+        }
+        case 7: {  // mode 1 with the persistent tile loop (one workgroup per CU walks its tiles)
+            const long nt = (p.N + 255) / 256;
+            const long t256 = ((p.M + 255) / 256) * nt * p.batches, t192 = ((p.M + 191) / 192) * nt * p.batches;
+            const long c256 = ((t256 + 255) / 256) * 256, c192 = ((t192 + 255) / 256) * 192;
+            return c192 * 11 < c256 * 10 ? big_go<T, 96, 128, 2, 2, 4, true>(p, stream) : big_go<T, 128, 128, 2, 2, 4, true>(p, stream);
         }
         case 5: return big_go<T, 128, 128, 2, 2>(p, stream);  // 256x256 forced
         case 6: return big_go<T, 96, 128, 2, 2>(p, stream);   // 192x256 forced
@@ -411,7 +483,7 @@ hipError_t launch_gemm16_big(int dtype, const GemmParams& p, hipStream_t stream)
         // 192x256 tile (mode 1 picks the one that leaves fewer idle CU-rounds) wins on every shape of the path —
         // q|k|v 64 vs 72 us, fc1 99 vs 104, out_proj 33 vs 37 against two 128x256 workgroups per CU (mode 4), which
         // round 1 preferred for K = 768 when the epilogue's 8-byte stores were the longer part of a tile
-        mode = 1;
+        mode = 7;  // round 3: mode 1's tiles, walked by one persistent workgroup per CU (bit-identical; q|k|v 70.9 -> 66.4 us)
     }
     return dtype == BF16 ? big_mode<bf16_tag>(mode, p, stream) : big_mode<f16_tag>(mode, p, stream);
 }

@@ -334,7 +334,6 @@ double tile_efficiency(const GemmParams& p, int tm, int cus) {
 
 }  // namespace
 
-namespace {
 int device_cus() {
     static int cus = 0;
     if (!cus) {
@@ -346,7 +345,6 @@ int device_cus() {
     }
     return cus;
 }
-}  // namespace
 
 int gemm_tile_pick(int mode, const GemmParams& p) {
     const int cus = device_cus();

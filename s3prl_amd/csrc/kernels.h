@@ -6,6 +6,7 @@
 #include "common.h"
 
 namespace s3 {
+int device_cus();  // gemmt.hip: CUs of the device the process first launched on (256 on an MI355X)
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel instantiation, device) instead of once per launch:
 // the call costs several microseconds of host time, and a forward is ~290-560 launches.

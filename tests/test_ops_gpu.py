@@ -59,12 +59,13 @@ def test_gemm_variants(dtype, case, variant):
         _lib.check(lib.s3enc_set_tuning(b"gemm_variant", 3))
 
 
-@pytest.mark.parametrize("mode", [1, 2, 4, 5, 6, 0])
+@pytest.mark.parametrize("mode", [1, 2, 4, 5, 6, 7, 0])
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("case", ["big_plain", "big_conv", "big_epilogue", "big_edge"])
 def test_gemm16_big_tiles(dtype, case, mode):
     """The large-tile LDS-DMA kernels of the 16-bit modes (gemm16.hip): 256x256 (mode 1) and 128x256 (mode 2) tiles on
-    shapes that span several tiles with ragged M / N edges, overlapping conv rows, batches and the full epilogue;
+    shapes that span several tiles with ragged M / N edges, overlapping conv rows, batches and the full epilogue; mode 7 = the
+    persistent tile loop (one workgroup per CU walks its tiles, the next tile's first K step issued before the epilogue);
     mode 0 runs the same shapes through the 128x128 kernel."""
     from s3prl_amd import _lib
 
@@ -565,3 +566,50 @@ def test_one_transcendental_gelu_is_at_fp32_rounding_level(scale):
         _lib.check(lib.s3enc_set_tuning(b"gelu32", 1))
     assert errs[0] < 1.0e-7, errs            # libm erff
     assert errs[1] < 1.5e-7, errs            # the one-transcendental form: the same level
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(1, 4500, 4100, 192, 1, False, False, True), (1, 5000, 3100, 128, 0, True, False, False),
+                                   (3, 2300, 2052, 256, 1, True, True, False), (1, 16000, 2304, 768, 0, False, False, True)])
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_gemm16_persistent_tile_loop_is_bit_identical(dtype, shape):
+    """gemm16_big = 7: one workgroup per CU walks its tiles (more tiles than CUs here: 306 / 260 / 243-324 / 567-756), issuing the
+    next tile's first K step before the current tile's epilogue.  Same MFMA order per accumulator as the one-tile-per-workgroup
+    launch (mode 1), so every output — 16-bit and fp32, GELU, residual, padded-row zeroing, ragged edges — must be bit-identical."""
+    torch = _torch()
+    from s3prl_amd import _lib
+
+    lib = _lib.load()
+    nb, M, N, K, act, use_res, use_lim, out16 = shape
+    code = {"bf16": 1, "fp16": 2}[dtype]
+    tdt = torch.bfloat16 if dtype == "bf16" else torch.float16
+    g = torch.Generator(device="cuda").manual_seed(zlib.crc32(repr(shape).encode()))
+    A = torch.randn(nb * M * K, device="cuda", generator=g).to(tdt)
+    W = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).to(tdt)
+    bias = torch.randn(N, device="cuda", generator=g)
+    res = torch.randn(nb * M * N, device="cuda", generator=g) if use_res else None
+    lim = torch.tensor([M - 300 * (b + 1) for b in range(nb)], dtype=torch.int32, device="cuda") if use_lim else None
+    outs = []
+    try:
+        for mode in (1, 7):
+            _lib.check(lib.s3enc_set_tuning(b"gemm16_big", mode))
+            o32 = None if out16 else torch.full((nb * M * N,), float("nan"), device="cuda")
+            o16 = torch.full((nb * M * N,), float("nan"), device="cuda").to(tdt) if out16 else None
+            _lib.check(lib.s3enc_op_gemm(code, _ptr(A), K, M * K, _ptr(W), _ptr(bias), M, N, K, nb, act, _ptr(res) if use_res else None,
+                                         _ptr(lim) if use_lim else None, _ptr(o32) if o32 is not None else None,
+                                         _ptr(o16) if o16 is not None else None, N, M * N, None))
+            torch.cuda.synchronize()
+            outs.append(o16 if out16 else o32)
+    finally:
+        _lib.check(lib.s3enc_set_tuning(b"gemm16_big", 3))
+    assert torch.isfinite(outs[0].float()).all()
+    assert torch.equal(outs[0], outs[1]), "the persistent tile loop differs from one tile per workgroup"
+    # and the product itself, on a slice of rows of the first batch
+    rows = slice(0, 512)
+    ref = A[: M * K].view(M, K)[rows].double() @ W.double().T + bias.double()
+    if act:
+        ref = torch.nn.functional.gelu(ref)
+    if use_res:
+        ref = ref + res[: M * N].view(M, N)[rows].double()
+    got = outs[1][: M * N].view(M, N)[rows].double()
+    assert ((got - ref).norm() / ref.norm()).item() < (1e-2 if out16 else 1e-5)
