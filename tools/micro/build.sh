@@ -1,0 +1,14 @@
+#!/bin/bash
+# Build the standalone measurement binaries of tools/micro (cross-compiles for gfx950 without a GPU; run from the repo root, after
+# `python -c "import __graft_entry__ as g; g.build()"` — gemm32_lab links libs3enc.so).  The binaries are git-ignored but travel to
+# the GPU box with the snapshot; tools/round_profiles.sh runs them.
+set -e
+cd "$(dirname "$0")/../.."
+H="hipcc -O3 -std=c++17 --offload-arch=gfx950"
+$H -DS3_ATTN_PROBE -Is3prl_amd/csrc tools/micro/attn_lab.hip -o tools/micro/attn_lab
+$H -DS3_GEMM_PROBE -Is3prl_amd/csrc tools/micro/gemm16_lab.hip -o tools/micro/gemm16_lab
+$H tools/micro/gemm16_loop_probe.hip -o tools/micro/gemm16_loop_probe
+$H tools/micro/gemm_loop_probe.hip -o tools/micro/gemm_loop_probe
+$H tools/micro/mfma_peak.hip -o tools/micro/mfma_peak
+hipcc -O2 --offload-arch=gfx950 tools/micro/gemm32_lab.cpp -Iinclude -Ls3prl_amd -ls3enc -Wl,-rpath,'$ORIGIN/../../s3prl_amd' -o tools/micro/gemm32_lab
+ls -la tools/micro | grep -v "\.hip\|\.cpp\|\.sh"

@@ -1,7 +1,7 @@
 // gemm_loop_probe.hip — the steady-state loop of gemm_kernel<float, 64, GLDS> (gemm.hip) with its ingredients switchable, on
 // L2-resident operands: which of {LDS fragment reads, LDS-DMA staging, the per-stage wait + barrier} takes the matrix pipe
 // from the 0.99 of a pure MFMA stream (mfma_peak.hip) to the 0.86 the GEMM measures.  Results are garbage by design.
-// Build: hipcc -O3 --offload-arch=gfx950 gemm_loop_probe.hip -o gemm_loop_probe
+// Build: tools/micro/build.sh (hipcc -O3 --offload-arch=gfx950 tools/micro/gemm_loop_probe.hip -o tools/micro/gemm_loop_probe)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>

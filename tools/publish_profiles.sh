@@ -15,7 +15,7 @@ for f in $src/kernel_stats_*.md; do
     cat $f; } > profiles/${tag}_kernel_stats_$name.md
 done
 for f in $src/pmc_*.md; do [ -s $f ] && cp $f profiles/${tag}_$(basename $f); done
-for f in gemm32_lab_fp32 gemm32_lab_x3 attn_lab gemm16_lab parity; do [ -s $src/$f.md ] && cp $src/$f.md profiles/${tag}_$f.md; done
+for f in gemm32_lab_fp32 gemm32_lab_x3 attn_lab gemm16_lab gemm16_lab_persistent parity; do [ -s $src/$f.md ] && cp $src/$f.md profiles/${tag}_$f.md; done
 [ -s $src/traffic.json ] && cp $src/traffic.json profiles/traffic.json
 python - <<EOF
 import json,glob

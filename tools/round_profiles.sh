@@ -52,11 +52,13 @@ for d in fp16x2 fp32x3 fp32; do
   python bench.py --model wavlm_large --dtype $d --secs 15 --mixed $Q --steps 8 --warmup 1 > $out/bench_cfg4_wavlm_large_mixed_$d.json 2>/dev/null
 done
 # 5. micro labs (standalone binaries, seconds each)
-for b in gemm32_lab attn_lab gemm16_lab; do [ -x tools/micro/$b ] || echo "tools/micro/$b is not built" >&2; done
+for b in gemm32_lab attn_lab gemm16_lab gemm16_loop_probe; do [ -x tools/micro/$b ] || echo "tools/micro/$b is not built" >&2; done
 tools/micro/gemm32_lab 3 > $out/gemm32_lab_fp32.md 2>&1
 tools/micro/gemm32_lab 3 - x3 > $out/gemm32_lab_x3.md 2>&1
 tools/micro/attn_lab > $out/attn_lab.md 2>&1
 tools/micro/gemm16_lab > $out/gemm16_lab.md 2>&1
+tools/micro/gemm16_lab cmp 1 7 > $out/gemm16_lab_persistent.md 2>&1      # one tile per workgroup against the persistent tile loop
+tools/micro/gemm16_loop_probe > $out/gemm16_loop_probe.md 2>&1
 # 6. parity of every mode against the reference's own outputs
 python tools/parity_table.py > $out/parity.md 2> $out/parity.err
 # 7. a sibling model and the N-rank path, functionally (two ranks share this box's single GPU over a gloo rendezvous)
