@@ -91,7 +91,13 @@ static int compare(int argc, char** argv) {
 
 int main(int argc, char** argv) {
     if (argc > 1 && !strcmp(argv[1], "cmp")) return compare(argc, argv);
-    s3::g_tuning.gemm16_big = argc > 1 ? atoi(argv[1]) : 3;  // 3 = default (lock-step 256x256 / 192x256), 4 = 128x256 ring, two per CU
+    // the probes live in the one-tile-per-workgroup kernels: 1 = 256x256 / 192x256 (the tiles the default, persistent mode 7 walks),
+    // 4 = 128x256 ring, two per CU; under 3 / 7 the probe bits are ignored and every row would time the full product
+    s3::g_tuning.gemm16_big = argc > 1 ? atoi(argv[1]) : 1;
+    if (s3::g_tuning.gemm16_big == 3 || s3::g_tuning.gemm16_big == 7) {
+        printf("the probes need a one-tile-per-workgroup mode (1, 2, 4, 5, 6); use `cmp` for the persistent loop\n");
+        return 1;
+    }
     printf("gemm16_big mode %d\n", s3::g_tuning.gemm16_big);
     struct Shape { const char* name; int M, N, K, act, res; };
     const Shape shapes[] = {{"qkv 15968x2304x768", 15968, 2304, 768, 0, 0}, {"out_proj 15968x768x768", 15968, 768, 768, 0, 1},
