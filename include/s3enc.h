@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define S3ENC_VERSION 4
+#define S3ENC_VERSION 5
 #define S3ENC_MAX_CONV 16
 #define S3ENC_MAX_RES 4 /* resolutions of a multires-HuBERT U-net: up to 3 rate pairs, 7 encoder blocks */
 
@@ -191,6 +191,16 @@ int s3enc_comm_init_rank(const void* id128, int32_t world, int32_t rank, int32_t
 int s3enc_comm_info(s3enc_comm c, int32_t* world, int32_t* rank);
 int s3enc_comm_allgather_states(s3enc_comm c, const void* send, int64_t send_state_stride, void* recv, int64_t recv_state_stride,
                                 int32_t n_states, int64_t bytes_per_state, void* const* ready_events, void* stream);
+/* The same exchange with the algorithm chosen by the caller (ABI 5):
+ *   S3ENC_EXCHANGE_COLLECTIVE  one ncclAllGather per state — what s3enc_comm_allgather_states issues; RCCL picks ring / direct;
+ *   S3ENC_EXCHANGE_DIRECT      per state one group of world-1 ncclSend / ncclRecv pairs (peer = rank +- p): xGMI is
+ *                              point-to-point, every pair of GPUs has its own link, all 7 are driven at once.
+ * Identical result bytes; replaces nothing in the reference (see above).  With world = 1 both are one device copy. */
+#define S3ENC_EXCHANGE_COLLECTIVE 0
+#define S3ENC_EXCHANGE_DIRECT 1
+int s3enc_comm_exchange_states(s3enc_comm c, int32_t algo, const void* send, int64_t send_state_stride, void* recv,
+                               int64_t recv_state_stride, int32_t n_states, int64_t bytes_per_state, void* const* ready_events,
+                               void* stream);
 int s3enc_comm_destroy(s3enc_comm c);
 
 /* Same, for a zero-padded (B, row_stride) device buffer (what pad_sequence builds, hubert/expert.py:66). */

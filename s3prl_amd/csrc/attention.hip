@@ -390,7 +390,9 @@ __global__ __launch_bounds__(256, BIAS ? 2 : 3) void attn_h16_kernel(AttnParams 
             if (__builtin_expect(first || __any(mx > 8.f), 0)) {
                 // move the reference: exactly onto the maximum for the first keys of a row, up by the excess afterwards
                 const float delta = first ? mx : fmaxf(mx, 0.f);
-                const float alpha = __builtin_amdgcn_exp2f(-delta);  // first: O = l = 0, the scale is irrelevant
+                // first: O = l = 0 and the scale must be exactly 1 — exp2(-mx) overflows to +inf when every log2-domain score of
+                // the half is below -128 (q . b_k is softmax-invariant, so nothing bounds it) and 0 * inf would poison the row
+                const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     o0[r] *= alpha;

@@ -28,24 +28,24 @@ struct Rccl {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     std::string why;
 };
 
-Rccl& rccl() {
-    static Rccl r;
-    static bool tried = false;
-    if (tried) return r;
-    tried = true;
+Rccl load_rccl() {
+    Rccl r;
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char* n : names) {
         r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
         if (r.lib) break;
     }
     if (!r.lib) {
-        r.why = std::string("librccl.so.1 not found: ") + (dlerror() ? dlerror() : "");
+        const char* e = dlerror();  // ONE call: dlerror() clears the error it returns
+        r.why = std::string("librccl.so.1 not found: ") + (e ? e : "");
         return r;
     }
     auto sym = [&](const char* s) {
@@ -58,9 +58,17 @@ Rccl& rccl() {
     r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
     r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
     r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
+    r.Send = (decltype(r.Send))sym("ncclSend");
+    r.Recv = (decltype(r.Recv))sym("ncclRecv");
     r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
     r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
     r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+    return r;
+}
+
+// one rank per GPU may be a THREAD: the first calls of two ranks can race, so the table is a C++11 magic static
+Rccl& rccl() {
+    static Rccl r = load_rccl();
     return r;
 }
 
@@ -153,27 +161,61 @@ int s3enc_comm_info(s3enc_comm c, int32_t* world, int32_t* rank) {
     return 0;
 }
 
-int s3enc_comm_allgather_states(s3enc_comm c, const void* send, int64_t send_state_stride, void* recv, int64_t recv_state_stride,
-                                int32_t n_states, int64_t bytes_per_state, void* const* ready_events, void* stream) {
+// algo S3ENC_EXCHANGE_COLLECTIVE: one ncclAllGather per state (RCCL chooses ring / tree / direct by its own tuning);
+// algo S3ENC_EXCHANGE_DIRECT: per state ONE group of world-1 ncclSend + world-1 ncclRecv, peer (rank +- p) mod world at step p —
+// every pair of GPUs owns its xGMI link (7 links x ~153 GB/s per GPU), so the all-pairs form drives all seven links at
+// once where a ring collective is bound by one (cfg4 bf16 at N = 8: 5.72 GB inbound per GPU = >= 5.3 ms direct against ~37 ms
+// through a single-link ring).  Both forms produce the same bytes in the same places.
+int s3enc_comm_exchange_states(s3enc_comm c, int32_t algo, const void* send, int64_t send_state_stride, void* recv,
+                               int64_t recv_state_stride, int32_t n_states, int64_t bytes_per_state, void* const* ready_events,
+                               void* stream) {
     Rccl& R = rccl();
     if (!R.lib || !R.why.empty()) return fail("s3enc_comm: " + R.why);
-    if (!c || !send || !recv || n_states < 1 || bytes_per_state < 1) return fail("s3enc_comm_allgather_states: bad arguments");
+    if (!c || !send || !recv || n_states < 1 || bytes_per_state < 1) return fail("s3enc_comm_exchange_states: bad arguments");
+    if (algo != S3ENC_EXCHANGE_COLLECTIVE && algo != S3ENC_EXCHANGE_DIRECT) return fail("s3enc_comm_exchange_states: unknown algo");
     if (recv_state_stride < bytes_per_state * c->world || send_state_stride < bytes_per_state)
-        return fail("s3enc_comm_allgather_states: a state stride is smaller than the block it holds");
+        return fail("s3enc_comm_exchange_states: a state stride is smaller than the block it holds");
     DeviceGuard dg(c->device);
     hipStream_t caller = (hipStream_t)stream;
     if (!ready_events) {  // no per-state events: the gathers simply follow everything enqueued on the caller's stream so far
         HIP_TRY(hipEventRecord(c->done, caller));
         HIP_TRY(hipStreamWaitEvent(c->stream, c->done, 0));
+    } else {
+        for (int l = 0; l < n_states; ++l)
+            if (!ready_events[l]) return fail("s3enc_comm_exchange_states: ready_events holds fewer than n_states events");
     }
     for (int l = 0; l < n_states; ++l) {
         if (ready_events) HIP_TRY(hipStreamWaitEvent(c->stream, (hipEvent_t)ready_events[l], 0));
-        RCCL_TRY(R.AllGather((const char*)send + (size_t)l * send_state_stride, (char*)recv + (size_t)l * recv_state_stride,
-                             (size_t)bytes_per_state, ncclInt8, c->comm, c->stream));
+        const char* src = (const char*)send + (size_t)l * send_state_stride;
+        char* dst = (char*)recv + (size_t)l * recv_state_stride;
+        if (algo == S3ENC_EXCHANGE_COLLECTIVE) {
+            RCCL_TRY(R.AllGather(src, dst, (size_t)bytes_per_state, ncclInt8, c->comm, c->stream));
+            continue;
+        }
+        char* own = dst + (size_t)c->rank * bytes_per_state;
+        if (own != src) HIP_TRY(hipMemcpyAsync(own, src, (size_t)bytes_per_state, hipMemcpyDeviceToDevice, c->stream));
+        if (c->world == 1) continue;
+        RCCL_TRY(R.GroupStart());
+        for (int pstep = 1; pstep < c->world; ++pstep) {
+            const int to = (c->rank + pstep) % c->world, from = (c->rank - pstep + c->world) % c->world;
+            ncclResult_t rs = R.Send(src, (size_t)bytes_per_state, ncclInt8, to, c->comm, c->stream);
+            ncclResult_t rr = rs ? rs : R.Recv(dst + (size_t)from * bytes_per_state, (size_t)bytes_per_state, ncclInt8, from, c->comm, c->stream);
+            if (rr != 0) {
+                (void)R.GroupEnd();
+                return fail(std::string("ncclSend / ncclRecv failed: ") + (R.GetErrorString ? R.GetErrorString(rr) : "?"));
+            }
+        }
+        RCCL_TRY(R.GroupEnd());
     }
     HIP_TRY(hipEventRecord(c->done, c->stream));
     HIP_TRY(hipStreamWaitEvent(caller, c->done, 0));  // the caller's later work sees the gathered states
     return 0;
+}
+
+int s3enc_comm_allgather_states(s3enc_comm c, const void* send, int64_t send_state_stride, void* recv, int64_t recv_state_stride,
+                                int32_t n_states, int64_t bytes_per_state, void* const* ready_events, void* stream) {
+    return s3enc_comm_exchange_states(c, S3ENC_EXCHANGE_COLLECTIVE, send, send_state_stride, recv, recv_state_stride, n_states,
+                                      bytes_per_state, ready_events, stream);
 }
 
 }  // extern "C"

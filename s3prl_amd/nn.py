@@ -227,7 +227,10 @@ class LegacyFeaturizer(nn.Module):
             f"the upstream returned {len(feature)} states, the weights were built for {self.layer_num} (an upstream with "
             "layer drop returns a varying number of states: select one layer instead, e.g. last_hidden_state)")
         norm_weights = F.softmax(self.weights, dim=-1)
-        if feature[0].is_cuda:  # the library's weighted sum (and, for training, its backward for the layer weights)
+        # the library's weighted sum (and, for training, its backward for the LAYER WEIGHTS) when the states are GPU-resident
+        # constants; states that carry a graph (a trainable upstream: the reference's `upstream_trainable` flow) need the
+        # gradient with respect to the states too, which only the torch form below propagates
+        if feature[0].is_cuda and not any(f.requires_grad for f in feature):
             return _WeightedSum.apply(norm_weights, self.normalize, *feature)
         stacked = torch.stack([f.float() for f in feature], dim=0)
         if self.normalize:

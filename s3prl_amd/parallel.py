@@ -28,7 +28,7 @@ def shard_bounds(B: int, world: int, rank: int) -> Tuple[int, int, int]:
 
 
 def encode_data_parallel(encode_fn: Callable[[List[torch.Tensor], int], torch.Tensor], wavs: Sequence[torch.Tensor],
-                         group=None, overlap_events: Optional[list] = None) -> List[torch.Tensor]:
+                         group=None, overlap_events: Optional[list] = None, algo: str = "ring") -> List[torch.Tensor]:
     """Every rank passes the SAME full list ``wavs`` (only its own shard has to be resident on its device);
     returns ``hidden_states``: NL+1 tensors of shape (B, T, D), identical on every rank, in input order.
 
@@ -47,7 +47,7 @@ def encode_data_parallel(encode_fn: Callable[[List[torch.Tensor], int], torch.Te
     hs = encode_fn(mine, n_max)  # (NL+1, per, T, D)
     if world == 1:
         return [hs[l][:B] for l in range(hs.shape[0])]
-    gathered = gather_layers(hs, group=group, overlap_events=overlap_events)
+    gathered = gather_layers(hs, group=group, overlap_events=overlap_events, algo=algo)
     # rank r's block holds utterances [r*per, r*per + per) → already in input order; drop the pad rows at the end
     return [gathered[l][:B] for l in range(gathered.shape[0])]
 
@@ -89,15 +89,43 @@ def featurized_data_parallel(expert, weights: Sequence[float], wavs: Sequence[to
 _COMM_STREAMS = {}
 
 
-def gather_layers(hs: torch.Tensor, group=None, overlap_events: Optional[list] = None,
-                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """All-gather a rank-local (NL+1, Bs, T, D) slab into (NL+1, world*Bs, T, D): ONE all-gather per layer, so every
-    ``hidden_states[l]`` comes out as a contiguous (B, T, D) block in rank order (a single flat gather would be
-    rank-major across layers, SURVEY §7 hard part 5).  With ``overlap_events`` (CUDA events recorded by the encoder
-    when layer l is final) the gather of layer l is issued on a side stream and overlaps the remaining compute."""
+EXCHANGE_ALGOS = ("ring", "direct")
+
+
+def _direct_exchange(out_l: torch.Tensor, hs_l: torch.Tensor, group, world: int, rank: int):
+    """All-pairs form of one state's exchange: rank r sends its block to every peer and receives theirs with world-1
+    point-to-point pairs (peer = rank +- p at step p), batched into ONE group.  xGMI is point-to-point — each pair of GPUs
+    has its own link — so this drives all 7 links of a GPU at once where a ring all-gather is bound by one.
+    Same bytes in the same places as ``all_gather_into_tensor``; works on every backend (gloo: the CPU tests)."""
     import torch.distributed as dist
 
+    Bs = hs_l.shape[0]
+    own = out_l[rank * Bs:(rank + 1) * Bs]
+    if own.data_ptr() != hs_l.data_ptr():
+        own.copy_(hs_l)
+    ops = []
+    for pstep in range(1, world):
+        to, frm = (rank + pstep) % world, (rank - pstep) % world
+        ops.append(dist.P2POp(dist.isend, hs_l, dist.get_global_rank(group, to) if group is not None else to, group))
+        ops.append(dist.P2POp(dist.irecv, out_l[frm * Bs:(frm + 1) * Bs],
+                              dist.get_global_rank(group, frm) if group is not None else frm, group))
+    return dist.batch_isend_irecv(ops) if ops else []
+
+
+def gather_layers(hs: torch.Tensor, group=None, overlap_events: Optional[list] = None,
+                  out: Optional[torch.Tensor] = None, algo: str = "ring") -> torch.Tensor:
+    """All-gather a rank-local (NL+1, Bs, T, D) slab into (NL+1, world*Bs, T, D): ONE exchange per layer, so every
+    ``hidden_states[l]`` comes out as a contiguous (B, T, D) block in rank order (a single flat gather would be
+    rank-major across layers, SURVEY §7 hard part 5).  With ``overlap_events`` (CUDA events recorded by the encoder
+    when layer l is final) the exchange of layer l is issued on a side stream and overlaps the remaining compute.
+    ``algo``: "ring" = one ``all_gather_into_tensor`` per layer (RCCL's own choice of algorithm), "direct" = the all-pairs
+    send / receive form (``_direct_exchange``)."""
+    import torch.distributed as dist
+
+    if algo not in EXCHANGE_ALGOS:
+        raise ValueError(f"algo must be one of {EXCHANGE_ALGOS}, got {algo!r}")
     world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
     NLp1, Bs, T, D = hs.shape
     if out is None:
         out = torch.empty((NLp1, world * Bs, T, D), dtype=hs.dtype, device=hs.device)
@@ -106,8 +134,16 @@ def gather_layers(hs: torch.Tensor, group=None, overlap_events: Optional[list] =
         # 16-bit states (s3enc_forward_ex out_dtype): an all-gather only moves bytes, so exchange them as uint8 — the one
         # element type every backend supports (gloo rejects bfloat16 and int16 on device tensors)
         hs, out = hs.view(torch.uint8), out.view(torch.uint8)
+
+    def one(l):
+        if algo == "direct":
+            return _direct_exchange(out[l], hs[l], group, world, rank)
+        return [dist.all_gather_into_tensor(out[l], hs[l], group=group, async_op=True)]
+
     works = []
     if overlap_events is not None and hs.is_cuda:
+        if len(overlap_events) < NLp1:
+            raise ValueError(f"{len(overlap_events)} overlap events for {NLp1} states")
         key = hs.device.index
         if key not in _COMM_STREAMS:
             _COMM_STREAMS[key] = torch.cuda.Stream(device=hs.device)
@@ -115,10 +151,10 @@ def gather_layers(hs: torch.Tensor, group=None, overlap_events: Optional[list] =
         for l in range(NLp1):
             with torch.cuda.stream(comm):
                 comm.wait_event(overlap_events[l])
-                works.append(dist.all_gather_into_tensor(out[l], hs[l], group=group, async_op=True))
+                works += one(l)
     else:
         for l in range(NLp1):
-            works.append(dist.all_gather_into_tensor(out[l], hs[l], group=group, async_op=True))
+            works += one(l)
     for w in works:
         w.wait()
     return result
@@ -146,29 +182,52 @@ class RcclComm:
             _lib.check(self._lib.s3enc_comm_unique_id(ident), "s3enc_comm_unique_id")
         if world > 1:
             box = [bytes(ident.raw)]
-            dist.broadcast_object_list(box, src=0, group=group)
+            # src is a GLOBAL rank: a subgroup need not contain global rank 0
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
             ident = C.create_string_buffer(box[0], 128)
         h = C.c_void_p()
         _lib.check(self._lib.s3enc_comm_init_rank(ident, world, rank, self.device, C.byref(h)), "s3enc_comm_init_rank")
-        self._h, self.world, self.rank = h, world, rank
+        self._h, self.world, self.rank, self._group = h, world, rank, group
+        self._checked_shapes = set()
 
-    def gather_layers(self, hs: torch.Tensor, overlap_events: Optional[list] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """(NS, Bs, T, D) on this rank -> (NS, world * Bs, T, D); asynchronous on the current stream."""
+    def _check_equal_slabs(self, shape):
+        """The exchange moves the same byte count from every rank: all ranks must hold the same (NS, Bs, T, D) (a ragged
+        last shard is padded to ceil(B / world) by ``encode_data_parallel`` before it gets here).  Checked once per shape."""
+        if self.world == 1 or shape in self._checked_shapes:
+            return
+        import torch.distributed as dist
+
+        shapes = [None] * self.world
+        dist.all_gather_object(shapes, tuple(shape), group=self._group)
+        if any(tuple(sh) != tuple(shape) for sh in shapes):
+            raise ValueError(f"RcclComm.gather_layers: slab shapes differ across ranks: {shapes}")
+        self._checked_shapes.add(shape)
+
+    def gather_layers(self, hs: torch.Tensor, overlap_events: Optional[list] = None, out: Optional[torch.Tensor] = None,
+                      algo: str = "ring") -> torch.Tensor:
+        """(NS, Bs, T, D) on this rank -> (NS, world * Bs, T, D); asynchronous on the current stream.
+        ``algo``: "ring" (ncclAllGather) or "direct" (grouped all-pairs ncclSend / ncclRecv) — S3ENC_EXCHANGE_* of the C ABI."""
         C = self._C
         from . import _lib
 
+        if algo not in EXCHANGE_ALGOS:
+            raise ValueError(f"algo must be one of {EXCHANGE_ALGOS}, got {algo!r}")
         NS = hs.shape[0]
         per_state = hs[0].numel() * hs.element_size()
         assert hs.is_cuda and hs[0].is_contiguous() and hs.stride(0) * hs.element_size() >= per_state
+        self._check_equal_slabs(tuple(hs.shape))
         if out is None:
             out = torch.empty((NS, self.world * hs.shape[1]) + tuple(hs.shape[2:]), dtype=hs.dtype, device=hs.device)
         evs = None
         if overlap_events is not None:
+            if len(overlap_events) < NS:
+                raise ValueError(f"{len(overlap_events)} overlap events for {NS} states")
             evs = (C.c_void_p * NS)(*[int(ev.cuda_event) for ev in overlap_events[:NS]])
         stream = torch.cuda.current_stream(hs.device).cuda_stream
-        _lib.check(self._lib.s3enc_comm_allgather_states(self._h, C.c_void_p(hs.data_ptr()), hs.stride(0) * hs.element_size(),
-                                                         C.c_void_p(out.data_ptr()), out.stride(0) * out.element_size(), NS,
-                                                         per_state, evs, C.c_void_p(stream)), "s3enc_comm_allgather_states")
+        _lib.check(self._lib.s3enc_comm_exchange_states(self._h, EXCHANGE_ALGOS.index(algo), C.c_void_p(hs.data_ptr()),
+                                                        hs.stride(0) * hs.element_size(), C.c_void_p(out.data_ptr()),
+                                                        out.stride(0) * out.element_size(), NS, per_state, evs,
+                                                        C.c_void_p(stream)), "s3enc_comm_exchange_states")
         return out
 
     def close(self):
@@ -186,11 +245,12 @@ class RcclComm:
 class DataParallelUpstream(torch.nn.Module):
     """Wraps a ``HipUpstreamExpert``: same ``forward(wavs) -> dict`` contract, batch sharded over the process group."""
 
-    def __init__(self, expert, group=None, overlap: bool = True):
+    def __init__(self, expert, group=None, overlap: bool = True, algo: str = "ring"):
         super().__init__()
         self.expert = expert
         self.group = group
         self.overlap = overlap
+        self.algo = algo
 
     def get_downsample_rates(self, key: str = None) -> int:
         return self.expert.get_downsample_rates(key)
@@ -199,7 +259,7 @@ class DataParallelUpstream(torch.nn.Module):
         events = None
         if self.overlap and wavs[0].is_cuda:
             events = self.expert._encoder_for(wavs[0].device).layer_events()
-        hidden = tuple(encode_data_parallel(self.expert.encode, wavs, self.group, events))
+        hidden = tuple(encode_data_parallel(self.expert.encode, wavs, self.group, events, self.algo))
         result = {"hidden_states": hidden, "last_hidden_state": hidden[-1]}
         for i, h in enumerate(hidden):
             result[f"hidden_state_{i}"] = h

@@ -112,3 +112,33 @@ def test_legacy_featurizer_on_the_hip_expert_matches_the_reference_class(name):
     if "feat_weights" in z:  # training the layer weights through the old interface: gradient from the HIP backward kernel
         sum(o.square().sum() for o in outs).backward()
         assert fz.weights.grad is not None and torch.isfinite(fz.weights.grad).all() and float(fz.weights.grad.abs().sum()) > 0
+
+
+def test_legacy_featurizer_backpropagates_into_states_that_carry_a_graph():
+    """interfaces.py:134-272: the reference's weighted sum is plain torch, so a trainable upstream (`upstream_trainable`) gets
+    its gradient through it.  The library's weighted sum only differentiates the layer weights: states with requires_grad
+    take the torch form instead of silently dropping their gradient."""
+    import torch
+    from s3prl_amd.nn import LegacyFeaturizer
+
+    L, B, T, D = 4, 2, 50, 64
+
+    class Up(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.scale = torch.nn.Parameter(torch.ones(L, device="cuda"))
+
+        def get_downsample_rates(self, key):
+            return 320
+
+        def forward(self, wavs):
+            base = torch.arange(L * B * T * D, device="cuda", dtype=torch.float32).view(L, B, T, D) / (L * B * T * D)
+            return {"hidden_states": [base[l] * self.scale[l] for l in range(L)]}
+
+    up = Up()
+    fz = LegacyFeaturizer(up, "hidden_states", upstream_device="cuda").cuda()
+    wavs = [torch.randn(16000, device="cuda") for _ in range(B)]
+    feats = fz(wavs, up(wavs))
+    torch.stack(feats).sum().backward()
+    assert up.scale.grad is not None and torch.all(up.scale.grad != 0)
+    assert fz.weights.grad is not None

@@ -14,7 +14,7 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, lengths, ret):
+def _worker(rank, world, port, lengths, ret, algo="ring"):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -31,7 +31,7 @@ def _worker(rank, world, port, lengths, ret):
         hs = O.forward(cfg, weights, [w.numpy() for w in shard], dtype=np.float32, n_max=n_max)
         return torch.from_numpy(np.stack(hs))
 
-    hidden = encode_data_parallel(encode_fn, wavs)
+    hidden = encode_data_parallel(encode_fn, wavs, algo=algo)
     if rank == 0:
         ret.put([h.numpy() for h in hidden])
     else:
@@ -40,15 +40,19 @@ def _worker(rank, world, port, lengths, ret):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,lengths", [(2, [4000, 2345, 3111, 800]), (3, [4000, 2345, 3111, 800]), (2, [3000, 1500, 2000])])
-def test_gloo_data_parallel_equals_full_batch(world, lengths):
+@pytest.mark.parametrize("world,lengths,algo", [(2, [4000, 2345, 3111, 800], "ring"), (3, [4000, 2345, 3111, 800], "ring"),
+                                                (2, [3000, 1500, 2000], "ring"),
+                                                # the all-pairs send / receive form of the exchange (xGMI is point-to-point)
+                                                (2, [4000, 2345, 3111, 800], "direct"), (3, [4000, 2345, 3111, 800], "direct"),
+                                                (3, [3000, 1500, 2000, 900, 1200], "direct")])
+def test_gloo_data_parallel_equals_full_batch(world, lengths, algo):
     from oracle import encoder_oracle as O
     from s3prl_amd.synth import named_config, synth_wavs, synth_weights
 
     ctx = mp.get_context("spawn")
     ret = ctx.Queue()
-    port = 29500 + (os.getpid() + world * 7 + len(lengths)) % 2000
-    procs = [ctx.Process(target=_worker, args=(r, world, port, lengths, ret)) for r in range(world)]
+    port = 29500 + (os.getpid() + world * 7 + len(lengths) + 13 * (algo == "direct")) % 2000
+    procs = [ctx.Process(target=_worker, args=(r, world, port, lengths, ret, algo)) for r in range(world)]
     for p in procs:
         p.start()
     results = [ret.get(timeout=240) for _ in range(world)]

@@ -170,4 +170,12 @@ def test_cabi_rccl_exchange_world_1():
     comm.gather_layers(hs, out=view)
     torch.cuda.synchronize()
     assert torch.equal(view, hs) and torch.isnan(flat[:, hs[0].numel():]).all()
+    # the all-pairs form (S3ENC_EXCHANGE_DIRECT: grouped ncclSend / ncclRecv, one peer per xGMI link): same layout contract
+    flat.fill_(float("nan"))
+    comm.gather_layers(hs, overlap_events=events, out=view, algo="direct")
+    torch.cuda.synchronize()
+    assert torch.equal(view, hs) and torch.isnan(flat[:, hs[0].numel():]).all()
+    assert torch.equal(comm.gather_layers(hs, algo="direct"), hs)
+    with pytest.raises(ValueError):
+        comm.gather_layers(hs, overlap_events=events[:2])  # fewer events than states must not reach hipStreamWaitEvent(NULL)
     comm.close()
