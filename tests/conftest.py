@@ -34,7 +34,7 @@ def load_golden(name):
     z = np.load(os.path.join(GOLDEN_DIR, f"{name}.npz"))
     meta = json.loads(bytes(z["meta"]).decode())
     cfg = named_config(meta["config"])
-    weights = synth_weights(cfg, meta["weight_seed"])
+    weights = synth_weights(cfg, meta["weight_seed"], meta.get("profile", "synthetic"))
     if meta.get("hf"):
         # Hugging Face fixtures: the checkpoint directory is re-written from the seeds (tests/hf_util.py) and read back by
         # the product reader s3prl_amd.hf (no transformers): its config carries HF's mask rule and normalisation eps

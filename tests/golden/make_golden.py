@@ -78,6 +78,18 @@ CASES = {
                                      {"selection": "fairseq_layers"}),
     "tiny_wav2vec2_large_fsbefore": ("tiny_wav2vec2_large", 6, 16, [3500, 4000, 1700], (1, 1), 0.0, 1.0,
                                      {"selection": "fairseq_layers_before_residual"}),
+    # round 4: released-checkpoint statistics (synth_weights(profile="pretrained_like"): residual-stream outlier channels,
+    # large LayerNorm gains, Student-t matrices, score-shifting q / k biases, near-silent / near-constant conv0 filters, a wide
+    # relative-position table) — what the reference's own regression test exercises by loading released checkpoints
+    # (test/test_upstream.py:118-136).  Models without waveform normalisation get int16-scale PCM with a DC offset.
+    "tiny_hubert_pl": ("tiny_hubert", 21, 51, [4000, 2345, 3111, 800], (1, 1), 60.0, 3000.0, {"profile": "pretrained_like"}),
+    "tiny_wavlm_large_pl": ("tiny_wavlm_large", 22, 52, [4000, 2345, 3111], (1, 1), 0.0, 1.0, {"profile": "pretrained_like"}),
+    "hubert_base_pl": ("hubert_base", 0, 53, [23456, 16000], (4, 8), 60.0, 3000.0, {"profile": "pretrained_like"}),
+    "wav2vec2_base_pl": ("wav2vec2_base", 0, 54, [20000, 27123], (4, 8), -35.0, 2000.0, {"profile": "pretrained_like"}),
+    "hubert_large_pl": ("hubert_large", 0, 55, [16000, 12000], (4, 16), 0.0, 1.0, {"profile": "pretrained_like"}),
+    "wavlm_large_pl": ("wavlm_large", 0, 56, [16000, 12000], (4, 16), 0.0, 1.0, {"profile": "pretrained_like"}),
+    "hubert_base_10s_pl": ("hubert_base", 1, 57, [160000, 123456], (8, 16), 60.0, 3000.0, {"profile": "pretrained_like"}),
+    "hubert_large_10s_pl": ("hubert_large", 1, 58, [160000, 160000], (8, 32), 0.0, 1.0, {"profile": "pretrained_like"}),
 }
 
 
@@ -218,7 +230,7 @@ def make_case(name: str):
     cfg_name, wseed, xseed, lengths, (ts, cs), dc, scale = CASES[name][:7]
     extras = CASES[name][7] if len(CASES[name]) > 7 else {}
     cfg = named_config(cfg_name)
-    weights = synth_weights(cfg, wseed)
+    weights = synth_weights(cfg, wseed, extras.get("profile", "synthetic"))
     wavs = synth_wavs(lengths, xseed, dc=dc, scale=scale)
     hs, out = reference_hidden_states(cfg, weights, wavs, extras)
     assert len(hs) == (cfg.encoder_layers if extras.get("selection") else cfg.num_hidden_states)

@@ -294,6 +294,44 @@ def test_attention(dtype, T, rel):
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16", "fp32x3"])
+def test_attention_with_every_score_far_below_zero(dtype):
+    """q . b_k shifts all scores of a query by the same amount — softmax-invariant, so nothing in training bounds it.  With
+    every score near -320 (log2 domain: -460) the first rescale of the 16-bit kernel would compute exp2(+460) = inf and
+    0 * inf = NaN for the whole row; the reference (and the result) is an ordinary softmax of the small differences."""
+    torch = _torch()
+    from s3prl_amd import _lib
+
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    B, T, H = 2, 150, 2
+    D = 64 * H
+    qkv = (0.1 * rng.standard_normal((B * T, 3 * D))).astype(np.float32)
+    qkv[:, :D] += 1.0
+    qkv[:, D:2 * D] -= 5.0
+    qkv[:, 2 * D:] = rng.standard_normal((B * T, D)).astype(np.float32)
+    valid = np.array([T, 70], dtype=np.int32)
+    qr = _round(qkv, dtype).astype(np.float64)
+    qdev = qkv
+    if dtype in ("bf16", "fp16"):
+        log2e = 1.4426950408889634
+        qdev = qkv.copy()
+        qdev[:, :D] = _round(qkv[:, :D] * np.float32(log2e), dtype)
+        qr[:, :D] = qdev[:, :D].astype(np.float64) / log2e
+    ref = _attention_ref(qr, valid, B, T, H, None, None, R=False)
+    dq = _dev(qdev, dtype)
+    out = torch.zeros((B * T, D), device="cuda", dtype=dq.dtype)
+    dvalid = torch.from_numpy(valid).cuda()
+    _lib.check(lib.s3enc_op_attention(_lib.DTYPES[dtype], _ptr(dq), _ptr(out), _ptr(dvalid), B, T, H, None, 0, None, None),
+               "s3enc_op_attention")
+    torch.cuda.synchronize()
+    got = out.float().cpu().numpy()
+    assert np.isfinite(got).all(), "NaN / inf rows: the first rescale multiplied 0 by exp2(+huge)"
+    err = O.rel_err(got, ref)
+    # the scores are ~320 in magnitude: their fp32 / 16-bit-operand rounding (not the kernel's bookkeeping) sets the error
+    assert err < {"fp32": 2e-4, "bf16": 6e-2, "fp16": 1e-2, "fp32x3": 5e-4}[dtype], f"{dtype}: rel-err {err:.3e}"
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16", "fp32x3"])
 @pytest.mark.parametrize("shape", [(2, 499, 768, 16, 128), (1, 300, 1024, 16, 128), (3, 70, 128, 4, 16), (2, 257, 768, 16, 128)])
 def test_posconv(dtype, shape):
     """Positional conv + GELU + residual (posconv.hip: fp32 Toeplitz kernel and the 16-bit implicit-GEMM kernel) against
