@@ -234,7 +234,8 @@ int s3enc_debug_tap(s3enc_handle h, const char* name, float* host_out, int64_t m
  *                   force 256 / 192 / 128 / 64 rows;  "gemm_x3_tile": the same for S3ENC_F32X3 (1 = only small shapes);
  *   "gemm16_big":   large-tile kernel of the 16-bit modes: 0 off, 1 = one workgroup per CU (256x256 or 192x256 tiles by CU
  *                   utilisation; 5 / 6 force either), 2 = 128x256, 4 = 128x256 with a 3-stage ring (two workgroups per
- *                   CU), 7 = mode 1's tiles walked by one persistent workgroup per CU, 3 = chosen by shape (default: 7);
+ *                   CU), 7 = mode 1's tiles walked by one persistent workgroup per CU, 8 = 7 with the epilogue's stores left
+ *                   draining under the next tile's first K steps (profiles/r04_gemm16_overlap.md), 3 = chosen by shape (default: 7);
  *   "gelu32":       S3ENC_F32 only: 1 = the one-transcendental erf-GELU every mode uses (default; csrc/common.h gelu_fast: as
  *                   close to an fp64 erf-GELU as 0.5 x (1 + erff(x / sqrt 2)) evaluated in fp32), 0 = libm erff — results
  *                   differ in the last bits. */

@@ -186,6 +186,11 @@ int s3enc_create(const s3enc_config* cfg, const s3enc_tensor* tensors, int32_t n
     } while (0)
 
     // ---- conv feature extractor ----
+    if (e->x2 && !c.extractor_layer_norm && !c.no_feature_layer_norm && c.n_conv >= 3 && C >= 128 && !(C & 31)) {
+        bool ok = true;  // every conv from the second on must be a shape the three-term GEMM takes (gemm_x3_eligible)
+        for (int i = 2; i < c.n_conv; ++i) ok = ok && !(((long)c.conv_kernel[i] * C) & 31) && !(((long)c.conv_stride[i] * C * 4) & 15);
+        if (ok) e->x2_conv_f32_from = 2;
+    }
     e->conv.resize(c.n_conv);
     for (int i = 0; i < c.n_conv; ++i) {
         const std::string p = "feature_extractor.conv_layers." + std::to_string(i);
@@ -200,7 +205,7 @@ int s3enc_create(const s3enc_config* cfg, const s3enc_tensor* tensors, int32_t n
                 for (int ci = 0; ci < cin; ++ci)
                     for (int j = 0; j < k; ++j) t2[((long)co * k + j) * cin + ci] = t[((long)co * cin + ci) * k + j];
             UP(upload_gemm_w(e->conv[i].w, t2, C, (long)k * cin, e->dtype, e->x2));
-            if (e->x3) UP(upload_x3(e->conv[i].w3, t2, C, (long)k * cin));
+            if (e->x3 || (e->x2_conv_f32_from && i >= e->x2_conv_f32_from)) UP(upload_x3(e->conv[i].w3, t2, C, (long)k * cin));
         }
         if (c.conv_bias) {
             GET(p + ".0.bias", C, t);
@@ -666,7 +671,7 @@ int forward_impl(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
     for (int pass = 0; pass < 2; ++pass) {
         Bump wb(pass ? e->ws.p : nullptr);
         actA = wb.take((size_t)B * L[0] * C * es);
-        actB = wb.take((size_t)B * L[1] * C * es);
+        actB = wb.take((size_t)B * L[1] * C * (e->x2_conv_f32_from ? 4 : es));  // (fp32 activations between the later convs)
         tmp32 = lnmode ? wb.take((size_t)B * L[1] * C * 4) : nullptr;
         feat32 = featln ? wb.take((size_t)M * C * 4) : nullptr;
         featT = wb.take((size_t)M * C * es);
@@ -734,7 +739,10 @@ int forward_impl(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
     void* cur = actA;
     for (int i = 1; i < c.n_conv; ++i) {
         const bool last = i == c.n_conv - 1;
-        const bool f32out = dt == F32 || (last && featln);
+        // S3ENC_F16X2, GroupNorm extractor: conv `x2_conv_f32_from`.. read fp32 activations through the three-term GEMM
+        const bool x3in = e->x2_conv_f32_from && i >= e->x2_conv_f32_from;
+        const bool x3next = e->x2_conv_f32_from && i + 1 >= e->x2_conv_f32_from && !last;
+        const bool f32out = dt == F32 || (last && featln) || x3next;
         void* dst = last ? (featln ? feat32 : featT) : (cur == actA ? actB : actA);
         GemmParams g{};
         g.A = cur;
@@ -750,14 +758,19 @@ int forward_impl(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
         g.ldo = C;
         g.o_bs = L[i] * C;
         const double fl = 2.0 * B * L[i] * C * g.K;
-        const double by = ((double)B * L[i - 1] * C + (double)C * g.K) * es + (double)B * L[i] * C * (f32out ? 4 : es);
+        const double by = ((double)B * L[i - 1] * C + (double)C * g.K) * (x3in ? 4 : es) + (double)B * L[i] * C * (f32out ? 4 : es);
         char kind[32];
         snprintf(kind, sizeof(kind), "gemm:conv%d", i);
         if (!lnmode) {
             g.act = 1;
             if (f32out) g.out32 = (float*)dst; else g.out16 = dst;
             Prof pr(e, st, kind, fl, by);
-            HIP_TRY(launch_gemm(dt, wsplit_of(e, g), st));
+            if (x3in) {
+                if (!gemm_x3_eligible(g)) return fail("conv layer is not a shape of the three-term GEMM (internal)");
+                HIP_TRY(launch_gemm(F32, g, st));
+            } else {
+                HIP_TRY(launch_gemm(dt, wsplit_of(e, g), st));
+            }
         } else {
             g.act = 0;
             g.out32 = (float*)tmp32;

@@ -252,6 +252,11 @@ struct s3enc_encoder {
     int dtype = F32;
     bool x3 = false;  // S3ENC_F32X3
     bool x2 = false;  // S3ENC_F16X2: fp16 data flow, GEMM weights as [hi | lo] fp16 halves (GemmParams.wsplit)
+    // S3ENC_F16X2 on a GroupNorm extractor (base models: conv1..6 are GELU-only, nothing renormalises between them): from
+    // this conv layer on, the stack runs on fp32 ACTIVATIONS through the three-term GEMM (gemm_x3.hip) instead of rounding
+    // every layer's output to fp16 — six stacked roundings are the largest single term of the mode's error on
+    // released-checkpoint statistics (tools/fp16_error_budget.py, profiles/r04_fp16_error_budget.md); 0 = off
+    int x2_conv_f32_from = 0;
     int es = 4;  // element size of the compute dtype
     std::vector<ConvW> conv;
     DevBuf gn_g, gn_b;

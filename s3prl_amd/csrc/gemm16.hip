@@ -74,8 +74,16 @@ template <> struct Mma16<f16_tag> {
 // first K step of the next tile by LDS-DMA before it starts the epilogue of the current one — the per-tile prologue (arguments,
 // addresses, a first stage with nothing to overlap it: ~2.5 us of a 24 us q|k|v tile, profiles/r03_gemm16_loop_probe.md) runs
 // under the epilogue, whose LDS staging moves out of stage 0's way (behind it).
-template <typename T, int WTM, int ROWB, int NST, int WPE, int WN, bool PERSIST = false>
+// OVL (PERSIST only; round 4): BOTH stages of the next tile are issued before the epilogue of the current one (its staging
+// shrinks to 4 KiB per wave and sits behind the two stages) and the next tile starts on a COUNTED vmcnt that skips the epilogue's
+// stores (vmcnt retires in order: the DMA pieces are older than the stores, so "all but the youngest S" = "the DMA has landed"),
+// which lets the store drain run under the next tile's first two K steps instead of in front of them.  A schedule change only:
+// same MFMA order per accumulator, bit-identical results.  Measured in profiles/r04_gemm16_overlap.md: -1.5...-4 % on the
+// multi-round K = 768 / 1024 shapes, +0.5...2 % on single-round ones, nothing on the forward — opt-in (`gemm16_big` = 8).
+// (A second option of that round — every thread touching one line of K step kt+2 a step ahead of its DMA — cost 12 % and was removed.)
+template <typename T, int WTM, int ROWB, int NST, int WPE, int WN, bool PERSIST = false, bool OVL_ = false>
 __global__ __launch_bounds__(128 * WN, WPE) void gemm16_big_kernel(GemmParams p) {
+    constexpr bool OVL = PERSIST && OVL_;
     constexpr int NTHR = 128 * WN;  // 2 waves along M x WN along N
     constexpr int BM = 2 * WTM, BN = 64 * WN;
     constexpr int MI = WTM / 32;  // 32-row accumulator blocks per wave
@@ -183,11 +191,27 @@ __global__ __launch_bounds__(128 * WN, WPE) void gemm16_big_kernel(GemmParams p)
 #pragma unroll
         for (int pc = 0; pc < NL; ++pc) issue_piece(pc, kt, stage);
     };
+    constexpr int STG_WAVE = OVL ? 4096 : 8192;  // epilogue staging per wave: 32 x 32 / 32 x 64 fp32
+    constexpr int STG_OFF = OVL ? 2 * STAGE_BYTES : (PERSIST ? STAGE_BYTES : 0);
     // my DMA (all of it, or all but the newest stage's NLA + NLB instructions) has landed and my fragment reads are
     // done; then everybody's
     auto barrier_all = [&]() {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+    };
+    auto barrier_lgkm = [&]() {  // my fragment reads are done (nothing of mine in the VM queue is needed by anybody yet)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+    // all but my youngest `n` VM operations have completed (n = the store instructions of the epilogue just behind the DMA)
+    auto wait_vm_keep = [&](int n) {
+        switch (n) {
+            case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+            case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+            case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+            case 32: asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        }
     };
     auto barrier_keep = [&]() {
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"i"((NST - 2) * (NLA + NLB)) : "memory");
@@ -275,153 +299,210 @@ __global__ __launch_bounds__(128 * WN, WPE) void gemm16_big_kernel(GemmParams p)
         return;
     }
 #endif
-    auto run_epilogue = [&]() {  // of tile (m0, n0, b)
-    // ---- epilogue through a wave-private LDS transpose: 32 x 64 fp32 per step ----
+    // Returns the number of global STORE instructions this wave issued when that number is fixed and nothing else of the
+    // epilogue entered the VM queue behind them (OVL: what the next tile's counted wait may leave in flight), else 0.
+    auto run_epilogue = [&](bool want_count) -> int {  // of tile (m0, n0, b)
+    // ---- epilogue through a wave-private LDS transpose: 32 x SW fp32 per round (SW = 64: both 32-column accumulator blocks of
+    // a 32-row block; OVL: 32, one accumulator block — 4 KiB per wave, so that the staging fits BESIDE both K stages) ----
     // Specialised at compile time on (GELU, residual, fp32 out, 16-bit out) for the four combinations the encoder uses
     // — the generic form tests five uniform flags per 4-row pass (168 branches per tile) — with a generic fallback.
     typedef typename Cvt<T>::store_t store_t;
-    float* stg = (float*)(smem + (PERSIST ? STAGE_BYTES : 0) + wave * 8192);
+    constexpr int NJ = OVL ? 1 : 2;   // accumulator blocks per staging round
+    constexpr int SW = 32 * NJ;       // staging row width (floats)
+    constexpr int NJB = 2 / NJ;       // staging rounds per 32-row block
+    float* stg = (float*)(smem + STG_OFF + wave * STG_WAVE);
     const int limit = p.row_limit ? p.row_limit[b] : p.M;
     const long ob = (long)b * p.o_bs;
-    const int c4 = (lane & 15) * 4;
-    const int n = n0 + wc * 64 + c4;
-    const bool n_ok = n < p.N;  // N % 4 == 0: a float4 is inside or outside as a whole
-    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p.bias && n_ok) bias4 = *(const float4*)(p.bias + n);
-    auto epilogue = [&](auto spec, auto act_c, auto res_c, auto o32_c, auto o16_c) {
+    // a tile with every row and column inside the product stores unconditionally: a fixed number of store instructions
+    const bool full_tile = m0 + BM <= p.M && n0 + BN <= p.N;
+    int n_stores = 0;
+    auto epilogue = [&](auto spec, auto act_c, auto res_c, auto o32_c, auto o16_c, auto full_c) {
         constexpr bool SPEC = decltype(spec)::value;
+        constexpr bool FULL = decltype(full_c)::value;
         const bool act = SPEC ? decltype(act_c)::value : (p.act != 0);
         const bool res = SPEC ? decltype(res_c)::value : (p.residual != nullptr);
         const bool o32 = SPEC ? decltype(o32_c)::value : (p.out32 != nullptr);
         const bool o16 = SPEC ? decltype(o16_c)::value : (p.out16 != nullptr);
         if constexpr (SPEC && decltype(o16_c)::value && !decltype(o32_c)::value && !decltype(res_c)::value) {
-            // 16-bit output only (conv1-5, q|k|v, fc1): 8 lanes x 8 columns per row, ONE 16-byte store per lane and pass
+            // 16-bit output only (conv1-5, q|k|v, fc1): SW / 8 lanes x 8 columns per row, ONE 16-byte store per lane and pass
             // (8-byte stores are issue-bound at 2.1-2.8 TB/s on this chip, 16-byte ones reach 5 TB/s: profiles/r02_gemm16_variants.md)
             // (16-byte stores: every row start of the 16-bit output must be 16-byte aligned, not just 8)
             if (!(p.N & 7) && !(p.ldo & 7) && !(p.o_bs & 7) && !((uintptr_t)p.out16 & 15)) {
-                const int c8 = (lane & 7) * 8;
-                const int n8 = n0 + wc * 64 + c8;
-                const bool n8_ok = n8 < p.N;
-                float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
-                if (p.bias && n8_ok) {
-                    b0 = *(const float4*)(p.bias + n8);
-                    b1 = *(const float4*)(p.bias + n8 + 4);
+                constexpr int LPR = SW / 8, RPS = 64 / LPR, NPASS = 32 / RPS;  // lanes per row, rows per pass, passes per round
+                const int c8 = (lane % LPR) * 8;
+                float4 b0[NJB], b1[NJB];
+#pragma unroll
+                for (int jb = 0; jb < NJB; ++jb) {
+                    const int n8 = n0 + wc * 64 + jb * SW + c8;
+                    b0[jb] = b1[jb] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (p.bias && (FULL || n8 < p.N)) {
+                        b0[jb] = *(const float4*)(p.bias + n8);
+                        b1[jb] = *(const float4*)(p.bias + n8 + 4);
+                    }
                 }
-                #pragma unroll
+#pragma unroll
                 for (int i = 0; i < MI; ++i) {
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
+                    for (int jb = 0; jb < NJB; ++jb) {
+                        const int n8 = n0 + wc * 64 + jb * SW + c8;
+                        const bool n8_ok = FULL || n8 < p.N;
 #pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            stg[((r & 3) + 8 * (r >> 2) + 4 * half) * 64 + j * 32 + l31] = acc[i][j][r];
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        for (int jj = 0; jj < NJ; ++jj)
 #pragma unroll
-                    for (int tt = 0; tt < 4; ++tt) {
-                        const int row = tt * 8 + (lane >> 3);
-                        float4 v = *(const float4*)(stg + row * 64 + c8);
-                        float4 w = *(const float4*)(stg + row * 64 + c8 + 4);
-                        const int m = m0 + wr * WTM + i * 32 + row;
-                        if (m < p.M && n8_ok) {
-                            v.x += b0.x; v.y += b0.y; v.z += b0.z; v.w += b0.w;
-                            w.x += b1.x; w.y += b1.y; w.z += b1.z; w.w += b1.w;
-                            if (act) {
-                                gelu_fast4(v);
-                                gelu_fast4(w);
+                            for (int r = 0; r < 16; ++r)
+                                stg[((r & 3) + 8 * (r >> 2) + 4 * half) * SW + jj * 32 + l31] = acc[i][jb * NJ + jj][r];
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                        for (int tt = 0; tt < NPASS; ++tt) {
+                            const int row = tt * RPS + lane / LPR;
+                            float4 v = *(const float4*)(stg + row * SW + c8);
+                            float4 w = *(const float4*)(stg + row * SW + c8 + 4);
+                            const int m = m0 + wr * WTM + i * 32 + row;
+                            if (FULL || (m < p.M && n8_ok)) {
+                                v.x += b0[jb].x; v.y += b0[jb].y; v.z += b0[jb].z; v.w += b0[jb].w;
+                                w.x += b1[jb].x; w.y += b1[jb].y; w.z += b1[jb].z; w.w += b1[jb].w;
+                                if (act) {
+                                    gelu_fast4(v);
+                                    gelu_fast4(w);
+                                }
+                                const long o = ob + (long)m * p.ldo + n8;
+                                const uint4 pk = make_uint4(Cvt<T>::pack2(v.x, v.y), Cvt<T>::pack2(v.z, v.w), Cvt<T>::pack2(w.x, w.y),
+                                                            Cvt<T>::pack2(w.z, w.w));
+                                if (S3_GPROBE(p, 16)) S3_GKEEP4(pk);
+                                else *(uint4*)((store_t*)p.out16 + o) = pk;
                             }
-                            const long o = ob + (long)m * p.ldo + n8;
-                            const uint4 pk = make_uint4(Cvt<T>::pack2(v.x, v.y), Cvt<T>::pack2(v.z, v.w), Cvt<T>::pack2(w.x, w.y),
-                                                        Cvt<T>::pack2(w.z, w.w));
-                            if (S3_GPROBE(p, 16)) S3_GKEEP4(pk);
-                            else *(uint4*)((store_t*)p.out16 + o) = pk;
                         }
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 }
+                if (FULL) n_stores = MI * NJB * NPASS;
                 return;
             }
+        }
+        constexpr int LPR = SW / 4, RPS = 64 / LPR, NPASS = 32 / RPS;
+        const int c4 = (lane % LPR) * 4;
+        float4 bias4[NJB];
+#pragma unroll
+        for (int jb = 0; jb < NJB; ++jb) {
+            const int n = n0 + wc * 64 + jb * SW + c4;
+            bias4[jb] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.bias && (FULL || n < p.N)) bias4[jb] = *(const float4*)(p.bias + n);  // N % 4 == 0: a float4 is inside or outside as a whole
         }
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int jb = 0; jb < NJB; ++jb) {
+                const int n = n0 + wc * 64 + jb * SW + c4;
+                const bool n_ok = FULL || n < p.N;
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    stg[((r & 3) + 8 * (r >> 2) + 4 * half) * 64 + j * 32 + l31] = acc[i][j][r];
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                for (int jj = 0; jj < NJ; ++jj)
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const int row = t * 4 + (lane >> 4);
-                float4 v = *(const float4*)(stg + row * 64 + c4);
-                const int m = m0 + wr * WTM + i * 32 + row;
-                if (m < p.M && n_ok) {
-                    v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
-                    if (act) {
-                        gelu_fast4(v);
-                    }
-                    const long o = ob + (long)m * p.ldo + n;
-                    if (res) {
-                        const float4 rs = *(const float4*)(p.residual + o);
-                        v.x += rs.x; v.y += rs.y; v.z += rs.z; v.w += rs.w;
-                    }
-                    if (!SPEC && m >= limit) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (S3_GPROBE(p, 16)) {
-                        S3_GKEEP4(v);
-                    } else {
-                        if (o32) *(float4*)(p.out32 + o) = v;
-                        if (o16) *(uint2*)((store_t*)p.out16 + o) = make_uint2(Cvt<T>::pack2(v.x, v.y), Cvt<T>::pack2(v.z, v.w));
+                    for (int r = 0; r < 16; ++r)
+                        stg[((r & 3) + 8 * (r >> 2) + 4 * half) * SW + jj * 32 + l31] = acc[i][jb * NJ + jj][r];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int t = 0; t < NPASS; ++t) {
+                    const int row = t * RPS + lane / LPR;
+                    float4 v = *(const float4*)(stg + row * SW + c4);
+                    const int m = m0 + wr * WTM + i * 32 + row;
+                    if (FULL || (m < p.M && n_ok)) {
+                        v.x += bias4[jb].x; v.y += bias4[jb].y; v.z += bias4[jb].z; v.w += bias4[jb].w;
+                        if (act) {
+                            gelu_fast4(v);
+                        }
+                        const long o = ob + (long)m * p.ldo + n;
+                        if (res) {
+                            const float4 rs = *(const float4*)(p.residual + o);
+                            v.x += rs.x; v.y += rs.y; v.z += rs.z; v.w += rs.w;
+                        }
+                        if (!SPEC && m >= limit) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (S3_GPROBE(p, 16)) {
+                            S3_GKEEP4(v);
+                        } else {
+                            if (o32) *(float4*)(p.out32 + o) = v;
+                            if (o16) *(uint2*)((store_t*)p.out16 + o) = make_uint2(Cvt<T>::pack2(v.x, v.y), Cvt<T>::pack2(v.z, v.w));
+                        }
                     }
                 }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
+        // (a residual epilogue loads between its stores: each wait for a load retires every older store as well — nothing to count)
+        if (FULL && SPEC && !decltype(res_c)::value && (decltype(o32_c)::value != decltype(o16_c)::value)) n_stores = MI * NJB * NPASS;
     };
     using TT = std::true_type;
     using FF = std::false_type;
     const bool a = p.act != 0, r = p.residual != nullptr, w32 = p.out32 != nullptr, w16 = p.out16 != nullptr;
-    if (p.row_limit) epilogue(FF{}, FF{}, FF{}, FF{}, FF{});                         // generic (proj: padded-frame zeroing)
-    else if (a && !r && !w32 && w16) epilogue(TT{}, TT{}, FF{}, FF{}, TT{});          // conv1-5, fc1
-    else if (!a && !r && !w32 && w16) epilogue(TT{}, FF{}, FF{}, FF{}, TT{});         // q|k|v
-    else if (!a && r && w32 && !w16) epilogue(TT{}, FF{}, TT{}, TT{}, FF{});          // out_proj, fc2
-    else if (a && !r && w32 && !w16) epilogue(TT{}, TT{}, FF{}, TT{}, FF{});          // last conv (feeds the fp32 LayerNorm)
-    else epilogue(FF{}, FF{}, FF{}, FF{}, FF{});
+    // FULL instantiations exist only where their fixed store count is used (OVL, a following tile, no residual loads)
+    const bool full = OVL && want_count && full_tile && !r && !p.row_limit && !S3_GPROBE(p, 16);
+    if (p.row_limit) epilogue(FF{}, FF{}, FF{}, FF{}, FF{}, FF{});                         // generic (proj: padded-frame zeroing)
+    else if (a && !r && !w32 && w16) {                                                     // conv1-5, fc1
+        if constexpr (OVL) { if (full) { epilogue(TT{}, TT{}, FF{}, FF{}, TT{}, TT{}); return n_stores; } }
+        epilogue(TT{}, TT{}, FF{}, FF{}, TT{}, FF{});
+    } else if (!a && !r && !w32 && w16) {                                                  // q|k|v
+        if constexpr (OVL) { if (full) { epilogue(TT{}, FF{}, FF{}, FF{}, TT{}, TT{}); return n_stores; } }
+        epilogue(TT{}, FF{}, FF{}, FF{}, TT{}, FF{});
+    } else if (!a && r && w32 && !w16) epilogue(TT{}, FF{}, TT{}, TT{}, FF{}, FF{});       // out_proj, fc2
+    else if (a && !r && w32 && !w16) epilogue(TT{}, TT{}, FF{}, TT{}, FF{}, FF{});         // last conv (feeds the fp32 LayerNorm)
+    else epilogue(FF{}, FF{}, FF{}, FF{}, FF{}, FF{});
+    return 0;
     };
     if constexpr (!PERSIST) {
-        run_epilogue();
+        (void)run_epilogue(false);
     } else {
-        issue(0, 0);
+        const bool two = OVL && nk > 1;  // the first TWO K steps of a tile go out together
+        auto issue_first = [&]() {
+            issue(0, 0);
+            if (two) issue(1, 1);
+        };
+        issue_first();
+        int pend = 0;  // store instructions of my epilogue that sit behind the DMA of the tile about to start
         for (;;) {
-            barrier_all();  // stage 0 of this tile has landed; every wave is done with the previous tile's epilogue staging
-            for (int kt = 0; kt < nk; ++kt) {
-                compute(kt & 1, kt + 1 < nk, kt + 1, (kt + 1) & 1);
+            // the first stage(s) of this tile have landed; every wave is done with the previous tile's epilogue staging
+            if constexpr (OVL) {
+                wait_vm_keep(pend);
+                barrier_lgkm();
+            } else {
                 barrier_all();
             }
             const int next = tile + tile_step;
             const bool has_next = next < tile_end;  // workgroup-uniform
-            if (has_next) {  // the next tile's first K step goes out before this tile's epilogue: both stage buffers are free
-                int nm0, nn0, nb;
-                coords(next, nm0, nn0, nb);
-                set_ptrs(nm0, nn0, nb);
-                issue(0, 0);
+            int nm0 = 0, nn0 = 0, nb = 0;
+            if (has_next) coords(next, nm0, nn0, nb);
+            for (int kt = 0; kt < nk; ++kt) {
+                const bool pre = two && kt == 0;        // K step 1 is already in flight (or landed)
+                compute(kt & 1, !pre && kt + 1 < nk, kt + 1, (kt + 1) & 1);
+                if (pre) barrier_lgkm();  // nothing of mine is awaited: K step 1 landed with the wait that opened the tile
+                else barrier_all();
             }
-            run_epilogue();
+            if (has_next) {  // the next tile's first K step(s) go out before this tile's epilogue: the stage buffers are free
+                set_ptrs(nm0, nn0, nb);
+                issue_first();
+            }
+            pend = run_epilogue(has_next);
             if (!has_next) break;
             tile = next;
-            coords(tile, m0, n0, b);
+            m0 = nm0;
+            n0 = nn0;
+            b = nb;
             zero_acc();
         }
     }
 }
 
-template <typename T, int WTM, int ROWB, int NST, int WPE, int WN = 4, bool PERSIST = false>
+template <typename T, int WTM, int ROWB, int NST, int WPE, int WN = 4, bool PERSIST = false, bool OVL_ = false>
 hipError_t big_go(const GemmParams& p, hipStream_t stream) {
     constexpr int BM = 2 * WTM, BN = 64 * WN, NTHR = 128 * WN;
-    constexpr int stage = (BM + BN) * ROWB, staging = 2 * WN * 8192;
-    // PERSIST: the epilogue's staging sits behind stage 0, which the next tile's first K step is landing in meanwhile
-    constexpr int lds = PERSIST ? (NST * stage > stage + staging ? NST * stage : stage + staging) : NST * stage;
+    constexpr bool OVL = PERSIST && OVL_;
+    constexpr int stage = (BM + BN) * ROWB, staging = 2 * WN * (OVL ? 4096 : 8192);
+    // PERSIST: the epilogue's staging sits behind stage 0, which the next tile's first K step is landing in meanwhile;
+    // OVL: behind BOTH stages (256 x 256: 128 + 32 KiB = all of a CU's LDS)
+    constexpr int lds = OVL ? NST * stage + staging : (PERSIST ? (NST * stage > stage + staging ? NST * stage : stage + staging) : NST * stage);
+    static_assert(!OVL || NST == 2, "OVL is written for the 2-stage pipeline");
     static_assert(lds >= staging, "epilogue staging must fit");
     static_assert(lds * (WPE * 4 * 64 / NTHR) <= 160 * 1024, "workgroups per CU x LDS");
-    auto kern = gemm16_big_kernel<T, WTM, ROWB, NST, WPE, WN, PERSIST>;
-    hipError_t e = ensure_dynamic_lds<gemm16_big_kernel<T, WTM, ROWB, NST, WPE, WN, PERSIST>>(lds);
+    auto kern = gemm16_big_kernel<T, WTM, ROWB, NST, WPE, WN, PERSIST, OVL_>;
+    hipError_t e = ensure_dynamic_lds<gemm16_big_kernel<T, WTM, ROWB, NST, WPE, WN, PERSIST, OVL_>>(lds);
     if (e != hipSuccess) return e;
     long tiles = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.batches;
     if (PERSIST) {
@@ -445,11 +526,13 @@ hipError_t big_mode(int mode, const GemmParams& p, hipStream_t stream) {
             // (the smaller tile is ~8 % less efficient per row: conv1 890 vs 840 TF at equal CU utilisation)
             return c192 * 11 < c256 * 10 ? big_go<T, 96, 128, 2, 2>(p, stream) : big_go<T, 128, 128, 2, 2>(p, stream);
         }
-        case 7: {  // mode 1 with the persistent tile loop (one workgroup per CU walks its tiles)
+        case 7: case 8: {  // mode 1 with the persistent tile loop (one workgroup per CU walks its tiles); 8: + OVL (see the kernel)
             const long nt = (p.N + 255) / 256;
             const long t256 = ((p.M + 255) / 256) * nt * p.batches, t192 = ((p.M + 191) / 192) * nt * p.batches;
             const long c256 = ((t256 + 255) / 256) * 256, c192 = ((t192 + 255) / 256) * 192;
-            return c192 * 11 < c256 * 10 ? big_go<T, 96, 128, 2, 2, 4, true>(p, stream) : big_go<T, 128, 128, 2, 2, 4, true>(p, stream);
+            const bool small = c192 * 11 < c256 * 10;
+            if (mode == 7) return small ? big_go<T, 96, 128, 2, 2, 4, true>(p, stream) : big_go<T, 128, 128, 2, 2, 4, true>(p, stream);
+            return small ? big_go<T, 96, 128, 2, 2, 4, true, true>(p, stream) : big_go<T, 128, 128, 2, 2, 4, true, true>(p, stream);
         }
         case 5: return big_go<T, 128, 128, 2, 2>(p, stream);  // 256x256 forced
         case 6: return big_go<T, 96, 128, 2, 2>(p, stream);   // 192x256 forced

@@ -59,7 +59,7 @@ def test_gemm_variants(dtype, case, variant):
         _lib.check(lib.s3enc_set_tuning(b"gemm_variant", 3))
 
 
-@pytest.mark.parametrize("mode", [1, 2, 4, 5, 6, 7, 0])
+@pytest.mark.parametrize("mode", [1, 2, 4, 5, 6, 7, 8, 0])
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("case", ["big_plain", "big_conv", "big_epilogue", "big_edge"])
 def test_gemm16_big_tiles(dtype, case, mode):
@@ -608,7 +608,12 @@ def test_one_transcendental_gelu_is_at_fp32_rounding_level(scale):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(1, 4500, 4100, 192, 1, False, False, True), (1, 5000, 3100, 128, 0, True, False, False),
-                                   (3, 2300, 2052, 256, 1, True, True, False), (1, 16000, 2304, 768, 0, False, False, True)])
+                                   (3, 2300, 2052, 256, 1, True, True, False), (1, 16000, 2304, 768, 0, False, False, True),
+                                   # full tiles with a following tile (the counted-vmcnt path of OVL), K = 64 (one K step) and
+                                   # K = 128 (two), a 16-bit output whose rows are only 8-byte aligned (the uint2-store fallback)
+                                   (1, 16384, 3072, 768, 1, False, False, True), (2, 8192, 1024, 64, 0, False, False, True),
+                                   (1, 12288, 2048, 128, 1, False, False, True), (1, 9000, 2052, 256, 0, False, False, True),
+                                   (1, 20480, 512, 1536, 1, False, False, False)])
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 def test_gemm16_persistent_tile_loop_is_bit_identical(dtype, shape):
     """gemm16_big = 7: one workgroup per CU walks its tiles (more tiles than CUs here: 306 / 260 / 243-324 / 567-756), issuing the
@@ -629,7 +634,7 @@ def test_gemm16_persistent_tile_loop_is_bit_identical(dtype, shape):
     lim = torch.tensor([M - 300 * (b + 1) for b in range(nb)], dtype=torch.int32, device="cuda") if use_lim else None
     outs = []
     try:
-        for mode in (1, 7):
+        for mode in (1, 7, 8):  # 8: the persistent loop with the epilogue stores left draining under the next tile (OVL)
             _lib.check(lib.s3enc_set_tuning(b"gemm16_big", mode))
             o32 = None if out16 else torch.full((nb * M * N,), float("nan"), device="cuda")
             o16 = torch.full((nb * M * N,), float("nan"), device="cuda").to(tdt) if out16 else None
@@ -641,7 +646,8 @@ def test_gemm16_persistent_tile_loop_is_bit_identical(dtype, shape):
     finally:
         _lib.check(lib.s3enc_set_tuning(b"gemm16_big", 3))
     assert torch.isfinite(outs[0].float()).all()
-    assert torch.equal(outs[0], outs[1]), "the persistent tile loop differs from one tile per workgroup"
+    for mode, o in zip((7, 8), outs[1:]):
+        assert torch.equal(outs[0], o), f"gemm16_big = {mode} differs from one tile per workgroup"
     # and the product itself, on a slice of rows of the first batch
     rows = slice(0, 512)
     ref = A[: M * K].view(M, K)[rows].double() @ W.double().T + bias.double()

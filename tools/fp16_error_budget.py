@@ -1,0 +1,140 @@
+#!/usr/bin/env python3
+"""Where does the fp16x2 mode's error come from?  (CPU, numpy fp64; test / design infrastructure — imports oracle/.)
+
+S3ENC_F16X2 keeps every GEMM weight as two fp16 terms, so only the ACTIVATIONS' fp16 rounding is left.  This script re-runs the
+transformer stack of a fixture in float64 with fp16 rounding injected at the sites where the HIP path stores a 16-bit operand
+(LayerNorm output -> q|k|v / fc1, q / k / v, the softmax probabilities, the attention output -> out_proj, GELU(fc1) -> fc2, the
+conv stack's activations) and reports the max-over-layers relative error with ALL sites rounded, with each site alone exact
+(what a two-term / fp32 operand THERE would buy) and with each site alone rounded.
+
+usage: tools/fp16_error_budget.py [golden fixture names ...]      (default: the post-LN pretrained-like base fixtures)
+"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+from conftest import load_golden
+from oracle import encoder_oracle as O
+
+SITES = ["conv", "feat", "ln_out", "q", "k", "v", "p", "attn_out", "fc1_out"]
+
+
+def r16(x):
+    return x.astype(np.float16).astype(np.float64)
+
+
+def run(cfg, W, wavs, rounded):
+    rd = lambda site, x: r16(x) if site in rounded else x
+    dt = np.float64
+    lens = [len(w) for w in wavs]
+    n_max = max(lens)
+    B = len(wavs)
+    padded = np.zeros((B, n_max))
+    for b, w in enumerate(wavs):
+        w = w.astype(dt)
+        if cfg.normalize:
+            w = O.wav_normalize(w, getattr(cfg, "wav_norm_eps", O.EPS))
+        padded[b, :lens[b]] = w
+    # conv stack: activations between the conv layers are 16-bit operands of the next conv GEMM
+    # "conv" = the outputs of conv0 .. conv(n-2) (the last conv feeds the fp32 LayerNorm / is rounded under "feat");
+    # "conv<=i" = only the outputs of conv0 .. conv i
+    upto = len(cfg.conv_layers) - 2 if "conv" in rounded else max([int(s[6:]) for s in rounded if s.startswith("conv<=")], default=-1)
+    feats = feature_extractor_rounded(cfg, W, padded, upto) if upto >= 0 else O.feature_extractor(cfg, W, padded, None)
+    T = feats.shape[1]
+    valid = [cfg.valid_frames(n, n_max) for n in lens]
+    x = feats
+    if cfg.feature_layer_norm:
+        x = O.layer_norm(x, W["layer_norm.weight"], W["layer_norm.bias"])
+    x = rd("feat", x) @ W["post_extract_proj.weight"].T + W["post_extract_proj.bias"]
+    for b in range(B):
+        x[b, valid[b]:] = 0
+    x = x + O.pos_conv(cfg, W, x)   # (the positional conv reads the fp32 stream; its operand rounding is counted under "feat")
+    if not cfg.layer_norm_first:
+        x = O.layer_norm(x, W["encoder.layer_norm.weight"], W["encoder.layer_norm.bias"])
+    H = cfg.encoder_attention_heads
+    D = x.shape[-1]
+    dh = D // H
+    hidden = []
+    for l in range(cfg.encoder_layers):
+        hidden.append(x)
+        p = f"encoder.layers.{l}"
+        ln1 = (W[f"{p}.self_attn_layer_norm.weight"], W[f"{p}.self_attn_layer_norm.bias"])
+        ln2 = (W[f"{p}.final_layer_norm.weight"], W[f"{p}.final_layer_norm.bias"])
+
+        def attn(a):
+            a = rd("ln_out", a)
+            q = (a @ W[f"{p}.self_attn.q_proj.weight"].T + W[f"{p}.self_attn.q_proj.bias"]) * dh ** -0.5
+            k = a @ W[f"{p}.self_attn.k_proj.weight"].T + W[f"{p}.self_attn.k_proj.bias"]
+            v = a @ W[f"{p}.self_attn.v_proj.weight"].T + W[f"{p}.self_attn.v_proj.bias"]
+            sp = lambda t: t.reshape(B, T, H, dh).transpose(0, 2, 1, 3)
+            q, k, v = sp(rd("q", q)), sp(rd("k", k)), sp(rd("v", v))
+            s = q @ k.transpose(0, 1, 3, 2)
+            for b in range(B):
+                s[b, :, :, valid[b]:] = -np.inf
+            s = s - s.max(-1, keepdims=True)
+            e = np.exp(s)
+            den = e.sum(-1, keepdims=True)           # the row sum is accumulated in fp32 from the unrounded probabilities
+            o = (rd("p", e) @ v) / den
+            o = o.transpose(0, 2, 1, 3).reshape(B, T, D)
+            return rd("attn_out", o) @ W[f"{p}.self_attn.out_proj.weight"].T + W[f"{p}.self_attn.out_proj.bias"]
+
+        def ffn(a):
+            h = O.gelu(rd("ln_out", a) @ W[f"{p}.fc1.weight"].T + W[f"{p}.fc1.bias"])
+            return rd("fc1_out", h) @ W[f"{p}.fc2.weight"].T + W[f"{p}.fc2.bias"]
+
+        if cfg.layer_norm_first:
+            x = x + attn(O.layer_norm(x, *ln1))
+            x = x + ffn(O.layer_norm(x, *ln2))
+        else:
+            x = O.layer_norm(x + attn(x), *ln1)
+            x = O.layer_norm(x + ffn(x), *ln2)
+    if cfg.layer_norm_first:
+        x = O.layer_norm(x, W["encoder.layer_norm.weight"], W["encoder.layer_norm.bias"])
+    hidden.append(x)
+    return hidden
+
+
+def feature_extractor_rounded(cfg, W, padded, upto):
+    """oracle feature_extractor with the OUTPUT of conv layers 0 .. upto rounded to fp16 (the next conv GEMM's operand)."""
+    taps = {}
+    orig = O.gelu
+    calls = [0]
+
+    def gelu_r(x):
+        calls[0] += 1
+        return r16(orig(x)) if calls[0] - 1 <= upto else orig(x)
+
+    O.gelu = gelu_r
+    try:
+        return O.feature_extractor(cfg, W, padded, taps)
+    finally:
+        O.gelu = orig
+
+
+def main():
+    names = sys.argv[1:] or ["wav2vec2_base_pl", "hubert_base_pl", "hubert_base_pseudo"]
+    for name in names:
+        meta, cfg, weights, wavs, golden, _ = load_golden(name)
+        W = {k: v.astype(np.float64) for k, v in weights.items()}
+        exact = run(cfg, W, wavs, set())
+        err = lambda hs: max(O.rel_err(h, e) for h, e in zip(hs, exact))
+        print(f"\n## {name} ({meta['config']}): max over hidden states of the relative error vs the exact fp64 evaluation\n")
+        print(f"| rounded to fp16 | error |\n|---|---:|")
+        allr = err(run(cfg, W, wavs, set(SITES)))
+        print(f"| every site | {allr:.2e} |")
+        others = [s for s in SITES if s != "conv"]
+        for i in range(len(cfg.conv_layers) - 1):
+            e1 = err(run(cfg, W, wavs, set(others) | {f"conv<={i}"}))
+            print(f"| every other site + the outputs of conv0..conv{i} (conv{i + 2}.. on fp32 activations) | {e1:.2e} |")
+            sys.stdout.flush()
+        for s in SITES:
+            e1 = err(run(cfg, W, wavs, set(SITES) - {s}))
+            e2 = err(run(cfg, W, wavs, {s}))
+            print(f"| every site but `{s}` | {e1:.2e} |")
+            print(f"| only `{s}` | {e2:.2e} |")
+            sys.stdout.flush()
+
+
+if __name__ == "__main__":
+    main()

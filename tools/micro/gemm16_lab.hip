@@ -34,6 +34,10 @@ static int compare(int argc, char** argv) {
                             {"fc1 15968x3072x768", 15968, 3072, 768, 1, 0}, {"fc2 15968x768x3072", 15968, 768, 3072, 0, 1},
                             {"conv2 255968x512x1536", 255968, 512, 1536, 1, 0}, {"L.qkv 15968x3072x1024", 15968, 3072, 1024, 0, 0},
                             {"L.fc1 15968x4096x1024", 15968, 4096, 1024, 1, 0}, {"L.fc2 15968x1024x4096", 15968, 1024, 4096, 0, 1}};
+    // `cmp8 ...`: every tile loads tile 0's panels (variant bit 3: all operands L2-resident — what each shape's launch costs when
+    // the memory side is free);  `cmpx ...`: fp16 operands with two-term weights (S3ENC_F16X2: W rows [hi | lo], 2K contraction)
+    const bool shared = !strcmp(argv[1], "cmp8");
+    const bool split = !strcmp(argv[1], "cmpx");
     int modes[8], nm = 0;
     for (int i = 2; i < argc && nm < 8; ++i) modes[nm++] = atoi(argv[i]);
     if (!nm) { modes[0] = 3; modes[1] = 7; nm = 2; }
@@ -42,7 +46,7 @@ static int compare(int argc, char** argv) {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
-    printf("| shape (bf16) |");
+    printf("| shape (%s%s) |", split ? "fp16x2" : "bf16", shared ? ", every tile reads tile 0's panels" : "");
     for (int c = 0; c < nm; ++c) printf(" gemm16_big = %d, us | TFLOP/s |", modes[c]);
     printf("\n|---|");
     for (int c = 0; c < nm; ++c) printf("---:|---:|");
@@ -52,28 +56,30 @@ static int compare(int argc, char** argv) {
         float *bias, *res, *o32;
         const long mn = (long)sh.M * sh.N;
         CK(hipMalloc(&A, (long)sh.M * sh.K * 2 + 256));
-        CK(hipMalloc(&W, (long)sh.N * sh.K * 2));
+        CK(hipMalloc(&W, (long)sh.N * sh.K * 2 * (split ? 2 : 1)));
         CK(hipMalloc(&o16, mn * 2));
         CK(hipMalloc(&o32, mn * 4));
         CK(hipMalloc(&res, mn * 4));
         CK(hipMalloc(&bias, sh.N * 4));
         fill16<<<2048, 256, 0, st>>>(A, (long)sh.M * sh.K, 1u, 1.0f);
-        fill16<<<2048, 256, 0, st>>>(W, (long)sh.N * sh.K, 2u, 0.05f);
+        fill16<<<2048, 256, 0, st>>>(W, (long)sh.N * sh.K * (split ? 2 : 1), 2u, 0.05f);
         CK(hipMemsetAsync(bias, 0, sh.N * 4, st));
         CK(hipMemsetAsync(res, 0, mn * 4, st));
         s3::GemmParams p{};
         p.A = A; p.lda = sh.K; p.a_bs = 0; p.W = W; p.bias = bias; p.M = sh.M; p.N = sh.N; p.K = sh.K; p.batches = 1;
         p.act = sh.act; p.residual = sh.res ? res : nullptr; p.row_limit = nullptr;
         p.out32 = sh.res ? o32 : nullptr; p.out16 = sh.res ? nullptr : (void*)o16; p.ldo = sh.N; p.o_bs = mn;
-        p.variant = 3;
+        p.variant = 3 | (shared ? 8 : 0);
+        p.wsplit = split ? 1 : 0;
         double best[8];
         for (int c = 0; c < nm; ++c) best[c] = 1e30;
         for (int r = 0; r < 4; ++r)
             for (int c = 0; c < nm; ++c) {
                 s3::g_tuning.gemm16_big = modes[c];
-                CK(s3::launch_gemm16_big(s3::BF16, p, st));
+                const int dt = split ? s3::F16 : s3::BF16;
+                CK(s3::launch_gemm16_big(dt, p, st));
                 CK(hipEventRecord(e0, st));
-                for (int k = 0; k < 30; ++k) CK(s3::launch_gemm16_big(s3::BF16, p, st));
+                for (int k = 0; k < 30; ++k) CK(s3::launch_gemm16_big(dt, p, st));
                 CK(hipEventRecord(e1, st));
                 CK(hipEventSynchronize(e1));
                 float ms;
@@ -81,7 +87,7 @@ static int compare(int argc, char** argv) {
                 if (r && ms / 30 < best[c]) best[c] = ms / 30;   // round 0 warms the clocks
             }
         printf("| %s |", sh.name);
-        for (int c = 0; c < nm; ++c) printf(" %.1f | %.0f |", best[c] * 1e3, 2.0 * sh.M * (double)sh.N * sh.K / best[c] * 1e-9);
+        for (int c = 0; c < nm; ++c) printf(" %.1f | %.0f |", best[c] * 1e3, 2.0 * sh.M * (double)sh.N * sh.K / best[c] * 1e-9);  // algorithmic FLOPs (fp16x2 runs twice the MFMAs)
         printf("\n");
         fflush(stdout);
         CK(hipFree(A)); CK(hipFree(W)); CK(hipFree(o16)); CK(hipFree(o32)); CK(hipFree(res)); CK(hipFree(bias));
@@ -90,7 +96,7 @@ static int compare(int argc, char** argv) {
 }
 
 int main(int argc, char** argv) {
-    if (argc > 1 && !strcmp(argv[1], "cmp")) return compare(argc, argv);
+    if (argc > 1 && !strncmp(argv[1], "cmp", 3)) return compare(argc, argv);
     // the probes live in the one-tile-per-workgroup kernels: 1 = 256x256 / 192x256 (the tiles the default, persistent mode 7 walks),
     // 4 = 128x256 ring, two per CU; under 3 / 7 the probe bits are ignored and every row would time the full product
     s3::g_tuning.gemm16_big = argc > 1 ? atoi(argv[1]) : 1;
