@@ -11,8 +11,10 @@ with N ranks, one per GPU; ``n_gpus`` in the JSON line is the world size RCCL re
 A "step" is one full ``UpstreamExpert.forward``: raw waveforms already resident in HBM -> all NL+1
 hidden_states in HBM.  With N > 1 every rank encodes its own shard and the batch's hidden states are re-assembled on
 every rank (inside the timed region):
-  --gather layers      one RCCL all-gather per layer, issued on a side stream as each layer becomes final (default)
+  --gather auto        (default) layers for fp32 / fp32x3, layers16 for the 16-bit compute dtypes
+  --gather layers      one RCCL all-gather per layer, issued on a side stream as each layer becomes final
   --gather layers16    the same with 16-bit states (bf16 / fp16 compute modes): half the bytes
+  --exchange-algo ring|direct   one all-gather per state, or its all-pairs send / receive form (one peer per xGMI link)
   --gather featurized  the Featurizer's weighted sum runs as the encoder's epilogue; ONE (B, T, D) all-gather
   --gather none        no exchange (what "exposed communication" is measured against)
 --scaling weak (default): --batch utterances per GPU;  --scaling strong: --global-batch utterances split over the ranks.
@@ -56,16 +58,36 @@ DTYPE_NAMES = {"fp32": "f32", "bf16": "bf16", "fp16": "f16", "fp32x3": "bf16x3 (
 DEFAULT_STEPS = {"fp32": 150, "fp32x3": 330, "bf16": 700, "fp16": 700, "fp16x2": 500}
 
 
+def csrc_sha16():
+    """Identity of the kernels a PMC record was measured on: sha256 over s3prl_amd/csrc/*.hip, *.h (sorted by name), 16 hex digits.
+    tools/pmc_to_traffic.py stamps every record of profiles/traffic.json with it (the GPU box has no .git)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "s3prl_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(path, model, dtype, batch, secs):
     """HBM-side bytes per launch of the dominant kernel, from the committed PMC passes of this same workload
-    (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md §HBM); None when no matching record is committed."""
+    (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md §HBM).  Returns (record or None, note or None): a record measured on other
+    kernels than the ones in this tree (its `csrc_sha16` stamp differs, or it carries none) is NOT quoted — the note says so."""
     try:
         for rec in json.load(open(path)):
             if (rec["model"], rec["dtype"], rec["batch"], rec["secs"]) == (model, dtype, batch, secs):
-                return rec
+                have = csrc_sha16()
+                if rec.get("csrc_sha16") == have:
+                    return rec, None
+                return None, (f"profiles/traffic.json holds a record of this workload measured on kernels {rec.get('csrc_sha16', '(unstamped, round <= 3)')}"
+                              f"{' at commit ' + rec['commit'] if rec.get('commit') else ''}; this tree's csrc is {have} — stale, not quoted "
+                              "(tools/round_profiles.sh re-measures it)")
     except (OSError, ValueError, KeyError):
         pass
-    return None
+    return None, None
 
 
 def flops_per_utt(cfg, n):
@@ -117,7 +139,12 @@ def parse_args(argv=None):
     ap.add_argument("--mixed", action="store_true",
                     help="mixed-length batch (BASELINE configs[4] recipe): utterance 0 has --secs, the rest "
                          "randint(1 s, --secs), seed 1234; frames are counted per utterance (sum of T_i)")
-    ap.add_argument("--gather", default="layers", choices=["layers", "layers16", "featurized", "none"])
+    ap.add_argument("--gather", default="auto", choices=["auto", "layers", "layers16", "featurized", "none"],
+                    help="auto (default): layers for fp32 / fp32x3, layers16 for the 16-bit compute dtypes (half the xGMI bytes: a "
+                         "16-bit step is too short to hide fp32 slabs behind, DESIGN §7)")
+    ap.add_argument("--exchange-algo", default="ring", choices=["ring", "direct"],
+                    help="ring: one all-gather per state (RCCL picks its algorithm); direct: per state one group of all-pairs "
+                         "send / receive — xGMI is point-to-point, every peer has its own link (S3ENC_EXCHANGE_DIRECT)")
     ap.add_argument("--exchange-via", default="torch", choices=["torch", "cabi"],
                     help="who issues the per-layer RCCL all-gathers: torch.distributed (default) or the library's own "
                          "s3enc_comm_* entry points (the path a non-Python binder uses; needs --backend nccl)")
@@ -166,7 +193,7 @@ def dry_run(args, world, rank):
         dist.init_process_group(args.backend if args.backend != "nccl" else "gloo")
     B = args.batch if args.scaling == "weak" else -(-args.global_batch // world)
     hs = torch.full((3, B, 5, 8), float(rank))
-    got = gather_layers(hs) if world > 1 else hs
+    got = gather_layers(hs, algo=args.exchange_algo) if world > 1 else hs
     ok = all(bool((got[:, r * B:(r + 1) * B] == r).all()) for r in range(world))
     if world > 1:
         t = torch.tensor([1.0 if ok else 0.0])
@@ -257,7 +284,10 @@ def main():
     frames_per_batch = sum(enc.num_frames(m) for m in lens)
     NL, D = cfg.encoder_layers, cfg.encoder_embed_dim
     NS = enc.num_states()
-    gather = args.gather if world > 1 else "none"
+    gather = args.gather
+    if gather == "auto":
+        gather = "layers16" if args.dtype in ("bf16", "fp16", "fp16x2") else "layers"
+    gather = gather if world > 1 else "none"
     if gather == "layers16" and args.dtype not in ("bf16", "fp16", "fp16x2"):
         raise SystemExit("--gather layers16 needs a 16-bit compute dtype")
     feat_w = torch.softmax(torch.linspace(-1.0, 1.0, NS), 0).tolist()  # a Featurizer's softmax(weights)
@@ -284,16 +314,16 @@ def main():
             if gather == "featurized":
                 feat = expert.encode_featurized(wavs, feat_w, n_max=n)
                 if exchange:
-                    dist.all_gather_into_tensor(gathered, feat)
+                    gather_layers(feat.unsqueeze(0), out=gathered.unsqueeze(0), algo=args.exchange_algo)
                 return feat
             hs = expert.encode(wavs, n_max=n, out_dtype=args.dtype if gather == "layers16" else None)
             if exchange and gather != "none":
                 # one all-gather per layer (hidden_states[l] stays a contiguous (B_global, T, D) block), issued on a
                 # side stream as soon as layer l is final so it overlaps the remaining layers' compute
                 if cabi is not None:
-                    cabi.gather_layers(hs, overlap_events=events, out=gathered)
+                    cabi.gather_layers(hs, overlap_events=events, out=gathered, algo=args.exchange_algo)
                 else:
-                    gather_layers(hs, overlap_events=events, out=gathered)
+                    gather_layers(hs, overlap_events=events, out=gathered, algo=args.exchange_algo)
             return hs
 
     def timed(k, exchange=True, profile=False):
@@ -334,17 +364,21 @@ def main():
         elapsed, prof_steps = timed(steps, True, not args.no_profile)
         prof = enc.profile_read()
         comm = None
-        if world > 1 and gather != "none":
+        if world > 1:  # always reported for N > 1: what the exchange moves and how much of it the compute does not hide
             k2 = max(3, min(steps, 30))
-            for _ in range(2):
-                step(False)
-            el2, _ = timed(k2, False, False)
+            el2 = elapsed / steps * k2
+            if gather != "none":
+                for _ in range(2):
+                    step(False)
+                el2, _ = timed(k2, False, False)
             per_state = B * T * D * (2 if gather == "layers16" else 4)
-            recv = (world - 1) * per_state * (1 if gather == "featurized" else NS)
-            comm = {"mode": gather, "bytes_received_per_gpu_per_step": int(recv),
+            recv = 0 if gather == "none" else (world - 1) * per_state * (1 if gather == "featurized" else NS)
+            comm = {"mode": gather, "algo": args.exchange_algo if gather != "none" else None,
+                    "via": (args.exchange_via if gather in ("layers", "layers16") else "torch") if gather != "none" else None,
+                    "bytes_received_per_gpu_per_step": int(recv),
                     "ms_per_step_without_exchange": round(el2 / k2 * 1e3, 3),
                     "exposed_ms_per_step": round((elapsed / steps - el2 / k2) * 1e3, 3),
-                    "steps_without_exchange": k2}
+                    "steps_without_exchange": k2 if gather != "none" else 0}
         breakdown, bd_steps = [], 3
         if not args.no_profile:
             enc.profile_reset()
@@ -414,10 +448,12 @@ def main():
         }
         if comm:
             line["comm"] = comm
-        tr = pmc_traffic(args.traffic, args.model, args.dtype, B, args.secs)
+        tr, tr_note = pmc_traffic(args.traffic, args.model, args.dtype, B, args.secs)
         if tr is not None:
             line["roofline"]["traffic"] = tr["gemm_bytes_per_launch"]
-            line["roofline"]["traffic_source"] = tr["source"]
+            line["roofline"]["traffic_source"] = tr["source"] + f"; kernels {tr['csrc_sha16']}" + (f", commit {tr['commit']}" if tr.get("commit") else "")
+        elif tr_note:
+            line["roofline"]["traffic_note"] = tr_note
         if world == 1 and not args.no_parity and cfg.family != "distiller":
             # checkers + CPU baseline only; never on the product path
             from oracle import encoder_oracle as O

@@ -46,3 +46,28 @@ def test_tools_and_scripts_are_syntactically_valid():
         py_compile.compile(path, doraise=True)
     for path in sorted(glob.glob(os.path.join(ROOT, "tools", "*.sh"))):
         subprocess.run(["bash", "-n", path], check=True)
+
+
+def test_direct_exchange_algo_in_the_n_rank_dry_run():
+    """--exchange-algo direct: the all-pairs send / receive form of the per-state exchange, three ranks over gloo."""
+    line = _run(["--gpus", "3", "--batch", "2", "--exchange-algo", "direct"])
+    assert line["n_gpus"] == 3 and line["exchange_ok"]
+
+
+def test_stale_traffic_record_is_not_quoted(tmp_path):
+    """roofline.traffic comes from committed PMC passes; a record measured on other kernels than this tree's (its csrc stamp
+    differs, or it has none) must not be quoted as if it were current."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    rec = {"model": "hubert_base", "dtype": "fp32", "batch": 32, "secs": 10.0, "gemm_bytes_per_launch": 123, "source": "x"}
+    path = tmp_path / "traffic.json"
+    path.write_text(json.dumps([rec]))
+    got, note = bench.pmc_traffic(str(path), "hubert_base", "fp32", 32, 10.0)
+    assert got is None and "stale" in note
+    path.write_text(json.dumps([dict(rec, csrc_sha16=bench.csrc_sha16(), commit="abc1234")]))
+    got, note = bench.pmc_traffic(str(path), "hubert_base", "fp32", 32, 10.0)
+    assert got["gemm_bytes_per_launch"] == 123 and note is None
+    assert bench.pmc_traffic(str(path), "hubert_large", "fp32", 32, 10.0) == (None, None)

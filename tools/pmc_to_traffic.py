@@ -17,7 +17,10 @@ for f in glob.glob(os.path.join(root, "*", "**", "*counter_collection.csv"), rec
             t[1] += float(r["Counter_Value"])
 fetch = 2.0 * 1024.0 * tot["FETCH_SIZE"][1] / max(1, tot["FETCH_SIZE"][0])
 write = 1024.0 * tot["WRITE_SIZE"][1] / max(1, tot["WRITE_SIZE"][0])
-rec = {"model": model, "dtype": dtype, "batch": int(batch), "secs": float(secs),
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # csrc_sha16: the identity of the kernels these counters were measured on (bench.py refuses a stale record)
+
+rec = {"model": model, "dtype": dtype, "batch": int(batch), "secs": float(secs), "csrc_sha16": bench.csrc_sha16(),
        "gemm_bytes_per_launch": round(fetch + write), "fetch_bytes_per_launch": round(fetch),
        "write_bytes_per_launch": round(write), "launches_profiled": tot["FETCH_SIZE"][0],
        "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --model {model} --dtype {dtype}` "
