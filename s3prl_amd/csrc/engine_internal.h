@@ -148,7 +148,9 @@ inline hipError_t upload_cvt(DevBuf& d, const std::vector<float>& v, int dtype) 
 }
 
 // Positional-conv weight (folded, [D][Dg][K] like nn.Conv1d.weight) -> the layout of the kernel of `dtype`:
-//   fp32   [G][K][Dg/16][Dg(co)][16]         (posconv_kernel: tap-major 16-deep input-channel chunks)
+//   fp32   [G][K][Dg/16][Dg(co)][16]         (posconv_kernel: tap-major 16-deep input-channel chunks; inside a row of 16 the
+//                                             four 16-byte slots are stored at slot ^ pc_w_swizzle(co): the kernel's
+//                                             ds_read_b128 of a (16 co) x (16 ci) fragment block is then bank-conflict free)
 //   16-bit [G][Dg(co)][k = tap*Dg + ci]       (posconv16_kernel: the W operand of the implicit GEMM)
 inline void pack_posconv(const std::vector<float>& w, int D, int G, int K, int dtype, std::vector<float>& out) {
     const int Dg = D / G;
@@ -159,7 +161,7 @@ inline void pack_posconv(const std::vector<float>& w, int D, int G, int K, int d
                 for (int k = 0; k < K; ++k) {
                     const float x = w[((long)(gi * Dg + n) * Dg + ci) * K + k];
                     if (dtype == F32)
-                        out[((((long)gi * K + k) * (Dg / 16) + ci / 16) * Dg + n) * 16 + ci % 16] = x;
+                        out[((((long)gi * K + k) * (Dg / 16) + ci / 16) * Dg + n) * 16 + ((((ci % 16) >> 2) ^ pc_w_swizzle(n)) << 2) + (ci & 3)] = x;
                     else
                         out[(((long)gi * Dg + n) * K + k) * Dg + ci] = x;
                 }

@@ -81,7 +81,13 @@ template <> struct Mma16<f16_tag> {
 // same MFMA order per accumulator, bit-identical results.  Measured in profiles/r04_gemm16_overlap.md: -1.5...-4 % on the
 // multi-round K = 768 / 1024 shapes, +0.5...2 % on single-round ones, nothing on the forward — opt-in (`gemm16_big` = 8).
 // (A second option of that round — every thread touching one line of K step kt+2 a step ahead of its DMA — cost 12 % and was removed.)
-template <typename T, int WTM, int ROWB, int NST, int WPE, int WN, bool PERSIST = false, bool OVL_ = false>
+// SWAP (round 4; only launched for the 16-bit-output epilogues: conv1-5, q|k|v, fc1): the two MFMA operands change places, so an
+// accumulator block holds the TRANSPOSED 32 x 32 tile — a lane owns ONE ROW of the output (32 lanes = 32 rows) and 16 of its 32
+// columns in groups of four consecutive ones.  Bias / GELU / conversion run on those registers and two v_permlane32_swap per
+// 8 bytes hand each lane a contiguous 16-byte piece of its row: the epilogue needs NO LDS transpose (256 KiB written + read per
+// tile before: the largest part of the 7 us a q|k|v tile spent in its epilogue).  Each product a * w and the order in which an
+// accumulator sums them are unchanged — results bit-identical (tests).
+template <typename T, int WTM, int ROWB, int NST, int WPE, int WN, bool PERSIST = false, bool OVL_ = false, bool SWAP = false>
 __global__ __launch_bounds__(128 * WN, WPE) void gemm16_big_kernel(GemmParams p) {
     constexpr bool OVL = PERSIST && OVL_;
     constexpr int NTHR = 128 * WN;  // 2 waves along M x WN along N
@@ -191,8 +197,8 @@ __global__ __launch_bounds__(128 * WN, WPE) void gemm16_big_kernel(GemmParams p)
 #pragma unroll
         for (int pc = 0; pc < NL; ++pc) issue_piece(pc, kt, stage);
     };
-    constexpr int STG_WAVE = OVL ? 4096 : 8192;  // epilogue staging per wave: 32 x 32 / 32 x 64 fp32
-    constexpr int STG_OFF = OVL ? 2 * STAGE_BYTES : (PERSIST ? STAGE_BYTES : 0);
+    constexpr int STG_WAVE = (OVL && !SWAP) ? 4096 : 8192;  // epilogue staging per wave: 32 x 32 / 32 x 64 fp32 (SWAP: none)
+    constexpr int STG_OFF = (OVL && !SWAP) ? 2 * STAGE_BYTES : (PERSIST ? STAGE_BYTES : 0);
     // my DMA (all of it, or all but the newest stage's NLA + NLB instructions) has landed and my fragment reads are
     // done; then everybody's
     auto barrier_all = [&]() {
@@ -258,7 +264,10 @@ __global__ __launch_bounds__(128 * WN, WPE) void gemm16_big_kernel(GemmParams p)
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) Mma16<T>::run(fa[i], fb[j], acc[i][j]);
+                for (int j = 0; j < 2; ++j) {
+                    if constexpr (SWAP) Mma16<T>::run(fb[j], fa[i], acc[i][j]);  // lane <-> row m, registers <-> columns n
+                    else Mma16<T>::run(fa[i], fb[j], acc[i][j]);                 // lane <-> column n, registers <-> rows m
+                }
         }
     };
 
@@ -301,7 +310,68 @@ __global__ __launch_bounds__(128 * WN, WPE) void gemm16_big_kernel(GemmParams p)
 #endif
     // Returns the number of global STORE instructions this wave issued when that number is fixed and nothing else of the
     // epilogue entered the VM queue behind them (OVL: what the next tile's counted wait may leave in flight), else 0.
+    // SWAP: the row-per-lane epilogue (16-bit output, optional bias / GELU; the launcher guarantees no residual, no fp32 output, no
+    // row limit, N % 8 == 0 and 16-byte aligned output rows).  Returns the wave's store count when it is fixed (full tile).
+    auto epilogue_rows = [&](auto full_c, auto act_c) -> int {
+        constexpr bool FULL = decltype(full_c)::value;
+        constexpr bool act = decltype(act_c)::value;
+        typedef typename Cvt<T>::store_t store_t;
+        const long ob = (long)b * p.o_bs;
+        // my 16 columns of a 32-column block: 8 q + 4 half + {0, 1, 2, 3}, q = 0..3
+        float4 bz[2][4];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n0 + wc * 64 + j * 32 + 8 * q + 4 * half;
+                bz[j][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p.bias && (FULL || n < p.N)) bz[j][q] = *(const float4*)(p.bias + n);
+            }
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int m = m0 + wr * WTM + i * 32 + l31;
+            const bool row_ok = FULL || m < p.M;
+            store_t* orow = (store_t*)p.out16 + ob + (long)m * p.ldo;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                unsigned pk[4][2];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float4 v = make_float4(acc[i][j][4 * q] + bz[j][q].x, acc[i][j][4 * q + 1] + bz[j][q].y,
+                                           acc[i][j][4 * q + 2] + bz[j][q].z, acc[i][j][4 * q + 3] + bz[j][q].w);
+                    if (act) gelu_fast4(v);
+                    pk[q][0] = Cvt<T>::pack2(v.x, v.y);
+                    pk[q][1] = Cvt<T>::pack2(v.z, v.w);
+                }
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    // lanes l (half 0) and l + 32 (half 1) own the same row: column groups q = 2 pr (half 0's four columns, then
+                    // half 1's) and q = 2 pr + 1.  After swap(x = group 2 pr, y = group 2 pr + 1): the lower lane holds group 2 pr
+                    // of BOTH halves (x: its own, y: its partner's) = columns 16 pr .. + 7, the upper lane group 2 pr + 1 of both
+                    // = columns 16 pr + 8 .. + 15
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(pk[2 * pr][0], pk[2 * pr + 1][0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(pk[2 * pr][1], pk[2 * pr + 1][1], false, false);
+                    const uint4 o = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                    const int n8 = n0 + wc * 64 + j * 32 + 16 * pr + 8 * half;
+                    if (row_ok && (FULL || n8 < p.N)) {
+                        if (S3_GPROBE(p, 16)) S3_GKEEP4(o);
+                        else *(uint4*)(orow + n8) = o;
+                    }
+                }
+            }
+        }
+        return FULL ? MI * 4 : 0;
+    };
     auto run_epilogue = [&](bool want_count) -> int {  // of tile (m0, n0, b)
+    if constexpr (SWAP) {
+        const bool full_tile = m0 + BM <= p.M && n0 + BN <= p.N;
+        const bool act = p.act != 0;  // workgroup-uniform: one branch per tile, not one per four values
+        if (OVL && want_count && full_tile && !S3_GPROBE(p, 16))
+            return act ? epilogue_rows(std::true_type{}, std::true_type{}) : epilogue_rows(std::true_type{}, std::false_type{});
+        if (act) (void)epilogue_rows(std::false_type{}, std::true_type{});
+        else (void)epilogue_rows(std::false_type{}, std::false_type{});
+        return 0;
+    } else {
     // ---- epilogue through a wave-private LDS transpose: 32 x SW fp32 per round (SW = 64: both 32-column accumulator blocks of
     // a 32-row block; OVL: 32, one accumulator block — 4 KiB per wave, so that the staging fits BESIDE both K stages) ----
     // Specialised at compile time on (GELU, residual, fp32 out, 16-bit out) for the four combinations the encoder uses
@@ -446,6 +516,7 @@ __global__ __launch_bounds__(128 * WN, WPE) void gemm16_big_kernel(GemmParams p)
     else if (a && !r && w32 && !w16) epilogue(TT{}, TT{}, FF{}, TT{}, FF{}, FF{});         // last conv (feeds the fp32 LayerNorm)
     else epilogue(FF{}, FF{}, FF{}, FF{}, FF{}, FF{});
     return 0;
+    }
     };
     if constexpr (!PERSIST) {
         (void)run_epilogue(false);
@@ -490,19 +561,20 @@ __global__ __launch_bounds__(128 * WN, WPE) void gemm16_big_kernel(GemmParams p)
     }
 }
 
-template <typename T, int WTM, int ROWB, int NST, int WPE, int WN = 4, bool PERSIST = false, bool OVL_ = false>
+template <typename T, int WTM, int ROWB, int NST, int WPE, int WN = 4, bool PERSIST = false, bool OVL_ = false, bool SWAP = false>
 hipError_t big_go(const GemmParams& p, hipStream_t stream) {
     constexpr int BM = 2 * WTM, BN = 64 * WN, NTHR = 128 * WN;
     constexpr bool OVL = PERSIST && OVL_;
-    constexpr int stage = (BM + BN) * ROWB, staging = 2 * WN * (OVL ? 4096 : 8192);
+    constexpr int stage = (BM + BN) * ROWB, staging = SWAP ? 0 : 2 * WN * (OVL ? 4096 : 8192);  // (SWAP: no LDS in the epilogue)
     // PERSIST: the epilogue's staging sits behind stage 0, which the next tile's first K step is landing in meanwhile;
     // OVL: behind BOTH stages (256 x 256: 128 + 32 KiB = all of a CU's LDS)
     constexpr int lds = OVL ? NST * stage + staging : (PERSIST ? (NST * stage > stage + staging ? NST * stage : stage + staging) : NST * stage);
     static_assert(!OVL || NST == 2, "OVL is written for the 2-stage pipeline");
     static_assert(lds >= staging, "epilogue staging must fit");
+    static_assert(!SWAP || PERSIST, "SWAP is instantiated for the persistent loop only");
     static_assert(lds * (WPE * 4 * 64 / NTHR) <= 160 * 1024, "workgroups per CU x LDS");
-    auto kern = gemm16_big_kernel<T, WTM, ROWB, NST, WPE, WN, PERSIST, OVL_>;
-    hipError_t e = ensure_dynamic_lds<gemm16_big_kernel<T, WTM, ROWB, NST, WPE, WN, PERSIST, OVL_>>(lds);
+    auto kern = gemm16_big_kernel<T, WTM, ROWB, NST, WPE, WN, PERSIST, OVL_, SWAP>;
+    hipError_t e = ensure_dynamic_lds<gemm16_big_kernel<T, WTM, ROWB, NST, WPE, WN, PERSIST, OVL_, SWAP>>(lds);
     if (e != hipSuccess) return e;
     long tiles = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.batches;
     if (PERSIST) {
@@ -526,13 +598,22 @@ hipError_t big_mode(int mode, const GemmParams& p, hipStream_t stream) {
             // (the smaller tile is ~8 % less efficient per row: conv1 890 vs 840 TF at equal CU utilisation)
             return c192 * 11 < c256 * 10 ? big_go<T, 96, 128, 2, 2>(p, stream) : big_go<T, 128, 128, 2, 2>(p, stream);
         }
-        case 7: case 8: {  // mode 1 with the persistent tile loop (one workgroup per CU walks its tiles); 8: + OVL (see the kernel)
+        case 7: case 8: case 9: case 10: {  // mode 1 with the persistent tile loop (one workgroup per CU walks its tiles);
+                                            // 8: + OVL; 9: + SWAP (row-per-lane epilogue) where the epilogue allows it; 10: + both
             const long nt = (p.N + 255) / 256;
             const long t256 = ((p.M + 255) / 256) * nt * p.batches, t192 = ((p.M + 191) / 192) * nt * p.batches;
             const long c256 = ((t256 + 255) / 256) * 256, c192 = ((t192 + 255) / 256) * 192;
             const bool small = c192 * 11 < c256 * 10;
-            if (mode == 7) return small ? big_go<T, 96, 128, 2, 2, 4, true>(p, stream) : big_go<T, 128, 128, 2, 2, 4, true>(p, stream);
-            return small ? big_go<T, 96, 128, 2, 2, 4, true, true>(p, stream) : big_go<T, 128, 128, 2, 2, 4, true, true>(p, stream);
+            // the row-per-lane epilogue: 16-bit output only, no residual / row limit, whole 16-byte pieces of a row
+            const bool rows_ok = mode >= 9 && p.out16 && !p.out32 && !p.residual && !p.row_limit && !(p.N & 7) && !(p.ldo & 7) &&
+                                 !(p.o_bs & 7) && !((uintptr_t)p.out16 & 15) && !((uintptr_t)p.bias & 15);
+            const bool ovl = mode == 8 || mode == 10;
+            if (rows_ok) {
+                if (ovl) return small ? big_go<T, 96, 128, 2, 2, 4, true, true, true>(p, stream) : big_go<T, 128, 128, 2, 2, 4, true, true, true>(p, stream);
+                return small ? big_go<T, 96, 128, 2, 2, 4, true, false, true>(p, stream) : big_go<T, 128, 128, 2, 2, 4, true, false, true>(p, stream);
+            }
+            if (ovl) return small ? big_go<T, 96, 128, 2, 2, 4, true, true>(p, stream) : big_go<T, 128, 128, 2, 2, 4, true, true>(p, stream);
+            return small ? big_go<T, 96, 128, 2, 2, 4, true>(p, stream) : big_go<T, 128, 128, 2, 2, 4, true>(p, stream);
         }
         case 5: return big_go<T, 128, 128, 2, 2>(p, stream);  // 256x256 forced
         case 6: return big_go<T, 96, 128, 2, 2>(p, stream);   // 192x256 forced

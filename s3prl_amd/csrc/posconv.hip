@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void posconv_kernel(PosConvParams p) {
     const float* xrow = xs + (wave * (16 * PC_FT) + l15) * RS + 4 * kk;  // frame tile f: + 16 f rows
     for (int j = 0; j < K; ++j) {
         if (j + 1 < K) wload(j + 1);
-        const float* wb = wl + (j & 1) * WSZ + l15 * 16 + 4 * kk;
+        const float* wb = wl + (j & 1) * WSZ + l15 * 16 + 4 * (kk ^ pc_w_swizzle(l15));  // (the pack stored slot kk there)
         const float* xa = xrow + j * RS;
 #pragma unroll
         for (int cc = 0; cc < NCC; ++cc) {

@@ -59,7 +59,7 @@ def test_gemm_variants(dtype, case, variant):
         _lib.check(lib.s3enc_set_tuning(b"gemm_variant", 3))
 
 
-@pytest.mark.parametrize("mode", [1, 2, 4, 5, 6, 7, 8, 0])
+@pytest.mark.parametrize("mode", [1, 2, 4, 5, 6, 7, 8, 9, 10, 0])
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("case", ["big_plain", "big_conv", "big_epilogue", "big_edge"])
 def test_gemm16_big_tiles(dtype, case, mode):
@@ -613,7 +613,11 @@ def test_one_transcendental_gelu_is_at_fp32_rounding_level(scale):
                                    # K = 128 (two), a 16-bit output whose rows are only 8-byte aligned (the uint2-store fallback)
                                    (1, 16384, 3072, 768, 1, False, False, True), (2, 8192, 1024, 64, 0, False, False, True),
                                    (1, 12288, 2048, 128, 1, False, False, True), (1, 9000, 2052, 256, 0, False, False, True),
-                                   (1, 20480, 512, 1536, 1, False, False, False)])
+                                   (1, 20480, 512, 1536, 1, False, False, False),
+                                   # the row-per-lane epilogue (modes 9 / 10) on ragged edges: N a multiple of 8 but not of the
+                                   # tile, M ragged, several batches, with and without GELU; conv-shaped (N = 512, long K)
+                                   (1, 5000, 2312, 256, 1, False, False, True), (3, 1100, 520, 192, 0, False, False, True),
+                                   (2, 31999, 512, 1536, 1, False, False, True)])
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 def test_gemm16_persistent_tile_loop_is_bit_identical(dtype, shape):
     """gemm16_big = 7: one workgroup per CU walks its tiles (more tiles than CUs here: 306 / 260 / 243-324 / 567-756), issuing the
@@ -634,7 +638,8 @@ def test_gemm16_persistent_tile_loop_is_bit_identical(dtype, shape):
     lim = torch.tensor([M - 300 * (b + 1) for b in range(nb)], dtype=torch.int32, device="cuda") if use_lim else None
     outs = []
     try:
-        for mode in (1, 7, 8):  # 8: the persistent loop with the epilogue stores left draining under the next tile (OVL)
+        for mode in (1, 7, 8, 9, 10):  # 8: + the epilogue's stores draining under the next tile (OVL); 9: + the row-per-lane
+                                       # epilogue without LDS (SWAP) where the epilogue is 16-bit-only; 10: both
             _lib.check(lib.s3enc_set_tuning(b"gemm16_big", mode))
             o32 = None if out16 else torch.full((nb * M * N,), float("nan"), device="cuda")
             o16 = torch.full((nb * M * N,), float("nan"), device="cuda").to(tdt) if out16 else None
@@ -646,7 +651,7 @@ def test_gemm16_persistent_tile_loop_is_bit_identical(dtype, shape):
     finally:
         _lib.check(lib.s3enc_set_tuning(b"gemm16_big", 3))
     assert torch.isfinite(outs[0].float()).all()
-    for mode, o in zip((7, 8), outs[1:]):
+    for mode, o in zip((7, 8, 9, 10), outs[1:]):
         assert torch.equal(outs[0], o), f"gemm16_big = {mode} differs from one tile per workgroup"
     # and the product itself, on a slice of rows of the first batch
     rows = slice(0, 512)

@@ -17,6 +17,22 @@ done
 for f in $src/pmc_*.md; do [ -s $f ] && cp $f profiles/${tag}_$(basename $f); done
 for f in gemm32_lab_fp32 gemm32_lab_x3 attn_lab gemm16_lab gemm16_lab_persistent parity; do [ -s $src/$f.md ] && cp $src/$f.md profiles/${tag}_$f.md; done
 [ -s $src/traffic.json ] && cp $src/traffic.json profiles/traffic.json
+# stamp the records measured on THIS tree's kernels with the commit they belong to (the GPU box has no .git; bench.py matches on
+# csrc_sha16 and quotes the commit)
+python - <<PYEOF
+import json, subprocess, sys
+sys.path.insert(0, '.')
+import bench
+have = bench.csrc_sha16()
+head = subprocess.run(['git', 'rev-parse', '--short', 'HEAD'], capture_output=True, text=True).stdout.strip()
+dirty = bool(subprocess.run(['git', 'status', '--porcelain', 's3prl_amd/csrc'], capture_output=True, text=True).stdout.strip())
+recs = json.load(open('profiles/traffic.json'))
+for r in recs:
+    if r.get('csrc_sha16') == have and not r.get('commit'):
+        r['commit'] = head + ('+uncommitted csrc changes' if dirty else '')
+json.dump(recs, open('profiles/traffic.json', 'w'), indent=1)
+print('traffic.json:', sum(r.get('csrc_sha16') == have for r in recs), 'of', len(recs), 'records match this tree (csrc', have + ')')
+PYEOF
 python - <<EOF
 import json,glob
 for f in sorted(glob.glob('profiles/${tag}_bench_*.json')):
