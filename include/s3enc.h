@@ -235,7 +235,10 @@ int s3enc_debug_tap(s3enc_handle h, const char* name, float* host_out, int64_t m
  *   "gemm16_big":   large-tile kernel of the 16-bit modes: 0 off, 1 = one workgroup per CU (256x256 or 192x256 tiles by CU
  *                   utilisation; 5 / 6 force either), 2 = 128x256, 4 = 128x256 with a 3-stage ring (two workgroups per
  *                   CU), 7 = mode 1's tiles walked by one persistent workgroup per CU, 8 = 7 with the epilogue's stores left
- *                   draining under the next tile's first K steps (profiles/r04_gemm16_overlap.md), 3 = chosen by shape (default: 7);
+ *                   draining under the next tile's first K steps (profiles/r04_gemm16_overlap.md), 9 / 10 = 7 / 8 with the
+ *                   row-per-lane epilogue (no LDS transpose) wherever it is legal, 3 = chosen by shape (default: 7);
+ *   "gemm16_rows":  1 (default) = under mode 7 the GELU epilogues with a 16-bit output (conv1-5, fc1) take the row-per-lane form
+ *                   (profiles/r04_gemm16_epilogue.md), 0 = never;
  *   "gelu32":       S3ENC_F32 only: 1 = the one-transcendental erf-GELU every mode uses (default; csrc/common.h gelu_fast: as
  *                   close to an fp64 erf-GELU as 0.5 x (1 + erff(x / sqrt 2)) evaluated in fp32), 0 = libm erff — results
  *                   differ in the last bits. */

@@ -232,7 +232,8 @@ int s3enc_create(const s3enc_config* cfg, const s3enc_tensor* tensors, int32_t n
     }
     GET("post_extract_proj.weight", (long)D * C, t);
     UP(upload_gemm_w(e->proj_w, t, D, C, e->dtype, e->x2));
-    if (e->x3) UP(upload_x3(e->proj_w3, t, D, C));
+    e->x2_proj_f32 = e->x2 && !c.no_feature_layer_norm && c.family != S3ENC_DISTILLER && D >= 128 && !(C & 31) && !(D & 3);
+    if (e->x3 || e->x2_proj_f32) UP(upload_x3(e->proj_w3, t, D, C));
     GET("post_extract_proj.bias", D, t);
     UP(upload_f32(e->proj_b, t));
 
@@ -674,7 +675,7 @@ int forward_impl(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
         actB = wb.take((size_t)B * L[1] * C * (e->x2_conv_f32_from ? 4 : es));  // (fp32 activations between the later convs)
         tmp32 = lnmode ? wb.take((size_t)B * L[1] * C * 4) : nullptr;
         feat32 = featln ? wb.take((size_t)M * C * 4) : nullptr;
-        featT = wb.take((size_t)M * C * es);
+        featT = wb.take((size_t)M * C * (e->x2_proj_f32 ? 4 : es));
         x32 = wb.take((size_t)M * D * 4);
         xpc = wb.take((size_t)M * D * 4);
         xT = wb.take((size_t)M * D * es);
@@ -788,11 +789,12 @@ int forward_impl(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
         cur = dst;
     }
     // LayerNorm(C) -> post_extract_proj (+ zero padded frames)
+    const bool proj32 = dt == F32 || (e->x2_proj_f32 && featln);  // the projection's operand stays fp32
     if (featln) {
-        Prof pr(e, st, "layernorm:feat", 0, (double)M * C * (4 + es));
+        Prof pr(e, st, "layernorm:feat", 0, (double)M * C * (4 + (proj32 ? 4 : es)));
         HIP_TRY(launch_layernorm(dt, (const float*)feat32, (const float*)e->fln_g.p, (const float*)e->fln_b.p, M, C, 0,
-                                 dt == F32 ? (float*)featT : nullptr, dt == F32 ? nullptr : featT, st));
-        e->taps["feat_ln"] = {featT, M * C, dt};
+                                 proj32 ? (float*)featT : nullptr, proj32 ? nullptr : featT, st));
+        e->taps["feat_ln"] = {featT, M * C, proj32 ? (int)F32 : dt};
     }
     const int si_proj = dist ? 0 : -1;  // DistilHuBERT: hidden_states[0] = feat_final, padded frames zeroed in place
     float* xproj = sink.slot32(si_proj) ? sink.slot32(si_proj) : (float*)x32;
@@ -815,7 +817,12 @@ int forward_impl(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
         g.o_bs = T * D;
         {
             Prof pr(e, st, "gemm:proj", 2.0 * M * D * C, ((double)M * C + (double)D * C) * es + (double)M * D * 4);
-            HIP_TRY(launch_gemm(dt, wsplit_of(e, g), st));
+            if (proj32 && dt != F32) {
+                if (!gemm_x3_eligible(g)) return fail("post_extract_proj is not a shape of the three-term GEMM (internal)");
+                HIP_TRY(launch_gemm(F32, g, st));
+            } else {
+                HIP_TRY(launch_gemm(dt, wsplit_of(e, g), st));
+            }
         }
         e->taps["proj"] = {xproj, M * D, F32};
         HIP_TRY(sink.emit(si_proj, xproj, false));

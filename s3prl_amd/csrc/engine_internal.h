@@ -259,6 +259,9 @@ struct s3enc_encoder {
     // every layer's output to fp16 — six stacked roundings are the largest single term of the mode's error on
     // released-checkpoint statistics (tools/fp16_error_budget.py, profiles/r04_fp16_error_budget.md); 0 = off
     int x2_conv_f32_from = 0;
+    // S3ENC_F16X2: post_extract_proj reads the fp32 LayerNorm(C) output through the three-term GEMM (0.4 % of the path's FLOPs;
+    // the rounding of its operand is the third-largest term of the mode's error budget)
+    bool x2_proj_f32 = false;
     int es = 4;  // element size of the compute dtype
     std::vector<ConvW> conv;
     DevBuf gn_g, gn_b;

@@ -605,8 +605,12 @@ hipError_t big_mode(int mode, const GemmParams& p, hipStream_t stream) {
             const long c256 = ((t256 + 255) / 256) * 256, c192 = ((t192 + 255) / 256) * 192;
             const bool small = c192 * 11 < c256 * 10;
             // the row-per-lane epilogue: 16-bit output only, no residual / row limit, whole 16-byte pieces of a row
-            const bool rows_ok = mode >= 9 && p.out16 && !p.out32 && !p.residual && !p.row_limit && !(p.N & 7) && !(p.ldo & 7) &&
-                                 !(p.o_bs & 7) && !((uintptr_t)p.out16 & 15) && !((uintptr_t)p.bias & 15);
+            // Measured (profiles/r04_gemm16_epilogue.md): a GELU epilogue gains 3-5 % from it (fc1 93.2 -> 88.7 us), a plain one
+            // LOSES 2-3 % (q|k|v 63.6 -> 64.7 us: its epilogue is store drain, and 32 rows x 32 bytes per store instruction drain
+            // slower than 8 rows x 128) — mode 7 (the default) therefore takes it for GELU epilogues only, 9 / 10 wherever it is legal
+            const bool rows_legal = p.out16 && !p.out32 && !p.residual && !p.row_limit && !(p.N & 7) && !(p.ldo & 7) &&
+                                    !(p.o_bs & 7) && !((uintptr_t)p.out16 & 15) && !((uintptr_t)p.bias & 15);
+            const bool rows_ok = rows_legal && (mode >= 9 || (mode == 7 && p.act != 0 && tuning().gemm16_rows != 0));
             const bool ovl = mode == 8 || mode == 10;
             if (rows_ok) {
                 if (ovl) return small ? big_go<T, 96, 128, 2, 2, 4, true, true, true>(p, stream) : big_go<T, 128, 128, 2, 2, 4, true, true, true>(p, stream);

@@ -32,6 +32,7 @@ struct Tuning {
     int gemm32_big = 1;    // gemmt.hip, fp32: 0 off, 1 = tile height by shape, 2..5 = force 256 / 192 / 128 / 64 rows
     int gemm_x3_tile = 1;  // gemmt.hip, S3ENC_F32X3: 0 off, 1 = only the shapes with few tiles, 2..5 = force a height
     int gemm16_big = 3;    // gemm16.hip: 0 off, 3 = choose by shape, 1 / 2 / 4 / 5 / 6 / 7 = force one configuration
+    int gemm16_rows = 1;   // gemm16.hip: 1 = GELU epilogues with a 16-bit output take the row-per-lane (no LDS) form, 0 = never
     int attn_lds_pad = 0;  // 16-bit attention occupancy probe
     int gelu32 = 1;        // S3ENC_F32: 1 = the one-transcendental GELU of every mode (common.h gelu_fast; fp32 rounding level), 0 = libm erff
     int x3_pack_cache = 0; // s3enc_op_gemm(S3ENC_F32X3): keep the packed image of the last weight (micro-benchmarks)
