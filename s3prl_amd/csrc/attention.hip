@@ -463,6 +463,17 @@ __global__ __launch_bounds__(256, BIAS ? 2 : 3) void attn_h16_kernel(AttnParams 
         if (!S3_PROBE(p, 16)) __syncthreads();
     }
     const float inv = 1.f / xhalf_sum(l_run);
+    if (p.out_f32) {  // (workgroup-uniform)
+        if (q_g < p.T) {
+            float* op = (float*)p.out + ((long)b * p.T + q_g) * D + head * HD + 4 * half;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                *(float4*)(op + 8 * g) = make_float4(o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
+                *(float4*)(op + 32 + 8 * g) = make_float4(o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+            }
+        }
+        return;
+    }
     if (q_g < p.T) {
         u16* op = (u16*)p.out + ((long)b * p.T + q_g) * D + head * HD + 4 * half;
 #pragma unroll

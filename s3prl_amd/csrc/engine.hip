@@ -310,6 +310,7 @@ int s3enc_create(const s3enc_config* cfg, const s3enc_tensor* tensors, int32_t n
     // (attention.hip: softmax as exp2 with no per-score multiply), so those handles fold log2(e) in as well — one rounding
     // of the weight to the operand type either way.  The exact-fp32 and split-precision handles keep the power-of-two scale.
     const float qscale = (1.0f / std::sqrt((float)(D / H))) * (e->dtype != F32 ? 1.44269504088896340736f : 1.0f);
+    e->x2_attn_f32 = e->x2 && !multires && D >= 128 && !(D & 31);  // (gemm_x3_eligible for N = K = D; the U-net keeps 16-bit)
     // one TransformerSentenceEncoderLayer named `p` (…layers.N); returns non-zero after fail() (e is already deleted)
     auto load_layer = [&](const std::string& p, LayerW& L) -> int {
         std::vector<float> w(3L * D * D), bb(3L * D);
@@ -326,7 +327,7 @@ int s3enc_create(const s3enc_config* cfg, const s3enc_tensor* tensors, int32_t n
         UP(upload_f32(L.bqkv, bb));
         GET(p + ".self_attn.out_proj.weight", (long)D * D, t);
         UP(upload_gemm_w(L.wo, t, D, D, e->dtype, e->x2));
-        if (e->x3) UP(upload_x3(L.wo3, t, D, D));
+        if (e->x3 || e->x2_attn_f32) UP(upload_x3(L.wo3, t, D, D));
         GET(p + ".self_attn.out_proj.bias", D, t);
         UP(upload_f32(L.bo, t));
         GET(p + ".self_attn_layer_norm.weight", D, t);
@@ -680,7 +681,7 @@ int forward_impl(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
         xpc = wb.take((size_t)M * D * 4);
         xT = wb.take((size_t)M * D * es);
         qkv = wb.take((size_t)M * 3 * D * es);
-        attn = wb.take((size_t)M * D * es);
+        attn = wb.take((size_t)M * D * (e->x2_attn_f32 ? 4 : es));
         tmp1 = wb.take((size_t)M * D * 4);
         tmp2 = wb.take((size_t)M * D * 4);
         hbuf = wb.take((size_t)M * HW * es);
@@ -972,9 +973,10 @@ int forward_impl(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
             a.bias_table = d_table;
             a.table_R = e->rel_R;
             a.gate = gated ? (const float*)gate : nullptr;
+            a.out_f32 = e->x2_attn_f32 ? 1 : 0;
             Prof pr(e, st, "attention", 4.0 * B * H * (double)T * T * 64, gM * 4 * D * es);
             HIP_TRY(launch_attention(e->x3 ? 3 : dt, a, st));
-            if (l == 0) e->taps["attn0"] = {attn, M * D, dt};
+            if (l == 0) e->taps["attn0"] = {attn, M * D, e->x2_attn_f32 ? (int)F32 : dt};
         }
         {   // out_proj + bias + residual
             GemmParams g{};
@@ -991,7 +993,12 @@ int forward_impl(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
             g.residual = x_cur;
             g.out32 = (float*)tmp1;
             Prof pr(e, st, "gemm:out_proj", 2.0 * gM * D * D, (gM * D + (double)D * D) * es + gM * D * 8);
-            HIP_TRY(launch_gemm(dt, wsplit_of(e, g), st));
+            if (e->x2_attn_f32) {
+                if (!gemm_x3_eligible(g)) return fail("out_proj is not a shape of the three-term GEMM (internal)");
+                HIP_TRY(launch_gemm(F32, g, st));
+            } else {
+                HIP_TRY(launch_gemm(dt, wsplit_of(e, g), st));
+            }
         }
         const float* ffn_res;
         const void* ffn_in;

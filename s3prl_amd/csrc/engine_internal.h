@@ -262,6 +262,10 @@ struct s3enc_encoder {
     // S3ENC_F16X2: post_extract_proj reads the fp32 LayerNorm(C) output through the three-term GEMM (0.4 % of the path's FLOPs;
     // the rounding of its operand is the third-largest term of the mode's error budget)
     bool x2_proj_f32 = false;
+    // S3ENC_F16X2: the attention output stays fp32 and out_proj reads it through the three-term GEMM (4 % of the path's FLOPs at
+    // 1.45x their two-term cost): the rounding of out_proj's operand is the largest non-conv term of the mode's error budget on
+    // released-checkpoint statistics (profiles/r04_fp16_error_budget.md)
+    bool x2_attn_f32 = false;
     int es = 4;  // element size of the compute dtype
     std::vector<ConvW> conv;
     DevBuf gn_g, gn_b;

@@ -151,6 +151,8 @@ struct AttnParams {
     const float* bias_table;  // WavLM: [H][2R+1], entry (h, clamp(key - query, -R, R) + R), or null
     int table_R = 0;
     const float* gate;        // WavLM: [B][H][T] or null (then gate = 1)
+    int out_f32 = 0;          // 16-bit kernels only: write the (B*T, D) result as fp32 (S3ENC_F16X2: out_proj then reads it
+                              // through the three-term GEMM — its operand's rounding is the largest non-conv term of the mode's error)
     int probe = 0;            // timing probes (tools/micro/attn_lab.hip builds the kernels with S3_ATTN_PROBE; ignored otherwise)
 };
 hipError_t launch_attention(int dtype, const AttnParams& p, hipStream_t s);
