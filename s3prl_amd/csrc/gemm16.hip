@@ -362,8 +362,17 @@ __global__ __launch_bounds__(128 * WN, WPE) void gemm16_big_kernel(GemmParams p)
         }
         return FULL ? MI * 4 : 0;
     };
-    auto run_epilogue = [&](bool want_count) -> int {  // of tile (m0, n0, b)
+    // `pre`: what the caller wants issued as early as the epilogue allows (the persistent loop: the next tile's first DMA).  A
+    // residual epilogue calls it BEHIND its first residual loads — vmcnt retires in order, so loads queued behind eight DMA
+    // pieces would return a stage-fetch later — every other epilogue at once.
+    auto run_epilogue = [&](bool want_count, auto&& pre) -> int {  // of tile (m0, n0, b)
+    bool pre_done = false;
+    auto do_pre = [&]() {
+        if (!pre_done) pre();
+        pre_done = true;
+    };
     if constexpr (SWAP) {
+        do_pre();
         const bool full_tile = m0 + BM <= p.M && n0 + BN <= p.N;
         const bool act = p.act != 0;  // workgroup-uniform: one branch per tile, not one per four values
         if (OVL && want_count && full_tile && !S3_GPROBE(p, 16))
@@ -389,6 +398,12 @@ __global__ __launch_bounds__(128 * WN, WPE) void gemm16_big_kernel(GemmParams p)
     auto epilogue = [&](auto spec, auto act_c, auto res_c, auto o32_c, auto o16_c, auto full_c) {
         constexpr bool SPEC = decltype(spec)::value;
         constexpr bool FULL = decltype(full_c)::value;
+        // residual epilogue (out_proj, fc2): the residual rows of a staging round are loaded one round AHEAD, before that round's
+        // LDS transpose.  In the forward the residual (the previous LayerNorm's fp32 output) is cold — Infinity Cache at best —
+        // and a load issued right before its use stalled every round for a memory round trip: out_proj / fc2 ran 46 / 105 us
+        // in the forward against 31 / 76 us on cache-warm operands in the lab (profiles/r04_gemm16_residual.md)
+        constexpr bool RESPF = SPEC && decltype(res_c)::value;
+        if constexpr (!RESPF) do_pre();
         const bool act = SPEC ? decltype(act_c)::value : (p.act != 0);
         const bool res = SPEC ? decltype(res_c)::value : (p.residual != nullptr);
         const bool o32 = SPEC ? decltype(o32_c)::value : (p.out32 != nullptr);
@@ -458,10 +473,26 @@ __global__ __launch_bounds__(128 * WN, WPE) void gemm16_big_kernel(GemmParams p)
             bias4[jb] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (p.bias && (FULL || n < p.N)) bias4[jb] = *(const float4*)(p.bias + n);  // N % 4 == 0: a float4 is inside or outside as a whole
         }
+        // (ONE register set: the row of pass t is re-loaded for the next round as soon as pass t has consumed it — a second set
+        // pushes the 256 x 256 tile's epilogue over 256 registers)
+        float4 rsb[RESPF ? NPASS : 1];
+        auto res_load1 = [&](int rd, int t) -> float4 {  // the residual of pass t of staging round rd = i * NJB + jb
+            const int i = rd / NJB, jb = rd % NJB;
+            const int n = n0 + wc * 64 + jb * SW + c4;
+            const int m = m0 + wr * WTM + i * 32 + t * RPS + lane / LPR;
+            if (FULL || (m < p.M && n < p.N)) return *(const float4*)(p.residual + ob + (long)m * p.ldo + n);
+            return make_float4(0.f, 0.f, 0.f, 0.f);
+        };
+        if constexpr (RESPF) {
+#pragma unroll
+            for (int t = 0; t < NPASS; ++t) rsb[t] = res_load1(0, t);
+            do_pre();
+        }
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
 #pragma unroll
             for (int jb = 0; jb < NJB; ++jb) {
+                const int rd = i * NJB + jb;
                 const int n = n0 + wc * 64 + jb * SW + c4;
                 const bool n_ok = FULL || n < p.N;
 #pragma unroll
@@ -482,7 +513,9 @@ __global__ __launch_bounds__(128 * WN, WPE) void gemm16_big_kernel(GemmParams p)
                         }
                         const long o = ob + (long)m * p.ldo + n;
                         if (res) {
-                            const float4 rs = *(const float4*)(p.residual + o);
+                            float4 rs;
+                            if constexpr (RESPF) rs = rsb[t];
+                            else rs = *(const float4*)(p.residual + o);
                             v.x += rs.x; v.y += rs.y; v.z += rs.z; v.w += rs.w;
                         }
                         if (!SPEC && m >= limit) v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -492,6 +525,9 @@ __global__ __launch_bounds__(128 * WN, WPE) void gemm16_big_kernel(GemmParams p)
                             if (o32) *(float4*)(p.out32 + o) = v;
                             if (o16) *(uint2*)((store_t*)p.out16 + o) = make_uint2(Cvt<T>::pack2(v.x, v.y), Cvt<T>::pack2(v.z, v.w));
                         }
+                    }
+                    if constexpr (RESPF) {
+                        if (rd + 1 < MI * NJB) rsb[t] = res_load1(rd + 1, t);  // in flight over the next round's LDS transpose
                     }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -519,7 +555,7 @@ __global__ __launch_bounds__(128 * WN, WPE) void gemm16_big_kernel(GemmParams p)
     }
     };
     if constexpr (!PERSIST) {
-        (void)run_epilogue(false);
+        (void)run_epilogue(false, []() {});
     } else {
         const bool two = OVL && nk > 1;  // the first TWO K steps of a tile go out together
         auto issue_first = [&]() {
@@ -546,11 +582,14 @@ __global__ __launch_bounds__(128 * WN, WPE) void gemm16_big_kernel(GemmParams p)
                 if (pre) barrier_lgkm();  // nothing of mine is awaited: K step 1 landed with the wait that opened the tile
                 else barrier_all();
             }
-            if (has_next) {  // the next tile's first K step(s) go out before this tile's epilogue: the stage buffers are free
-                set_ptrs(nm0, nn0, nb);
-                issue_first();
-            }
-            pend = run_epilogue(has_next);
+            // the next tile's first K step(s) go out before (a residual epilogue: just inside) this tile's epilogue: the stage
+            // buffers are free
+            pend = run_epilogue(has_next, [&]() {
+                if (has_next) {
+                    set_ptrs(nm0, nn0, nb);
+                    issue_first();
+                }
+            });
             if (!has_next) break;
             tile = next;
             m0 = nm0;

@@ -168,8 +168,23 @@ __global__ __launch_bounds__(512, 2) void gemm_x3_kernel(GemmParams p) {
     if (p.bias && n_ok) bias4 = *(const float4*)(p.bias + n);
     auto epilogue = [&](auto act_c, auto res_c) {
         constexpr bool ACT = decltype(act_c)::value, RES = decltype(res_c)::value;
+        // the residual rows of a 32-row block are loaded one block AHEAD, before that block's LDS transpose: in the forward the
+        // residual is cold and a load issued right before its use stalled every block for a memory round trip (see gemm16.hip)
+        float4 rsb[2][RES ? 8 : 1];
+        auto res_load = [&](int i, float4* dst) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int m = m0 + wr * WTM + i * 32 + t * 4 + (lane >> 4);
+                dst[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (m < p.M && n_ok) dst[t] = *(const float4*)(p.residual + ob + (long)m * p.ldo + n);
+            }
+        };
+        if constexpr (RES) res_load(0, rsb[0]);
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
+            if constexpr (RES) {
+                if (i + 1 < MI) res_load(i + 1, rsb[(i + 1) & 1]);
+            }
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -187,7 +202,7 @@ __global__ __launch_bounds__(512, 2) void gemm_x3_kernel(GemmParams p) {
                     }
                     const long o = ob + (long)m * p.ldo + n;
                     if (RES) {
-                        const float4 rs = *(const float4*)(p.residual + o);
+                        const float4 rs = rsb[i & 1][t];
                         v.x += rs.x; v.y += rs.y; v.z += rs.z; v.w += rs.w;
                     }
                     if (m >= limit) v = make_float4(0.f, 0.f, 0.f, 0.f);
