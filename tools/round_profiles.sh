@@ -3,10 +3,10 @@
 #   per BASELINE config: PMC passes (-> profiles/traffic.json record) -> bench (its JSON then carries roofline.traffic) ->
 #   rocprofv3 kernel-trace summary; the operand modes of the headline workload; the micro labs; the parity table.
 # Raw rocprof output stays on the box (only the summaries are merged back: gpurun_out is capped at 64 MiB).
-# usage: tools/round_profiles.sh r03        (most important artefacts first: a cut-off run still leaves them)
-#        PROFILE_ONLY="fp32 bf16" tools/round_profiles.sh r03   (PMC + rocprof only for the named configurations, bench lines for all)
+# usage: tools/round_profiles.sh r04        (most important artefacts first: a cut-off run still leaves them)
+#        PROFILE_ONLY="fp32 bf16" tools/round_profiles.sh r04   (PMC + rocprof only for the named configurations, bench lines for all)
 set -u
-tag=${1:-r03}
+tag=${1:-r04}
 export TMPDIR=/tmp
 out=gpurun_out/$tag
 mkdir -p $out
@@ -36,32 +36,36 @@ profile_cfg() {
 # 1. the metric's workload (HuBERT-base 32 x 10 s, fp32): PMC + traffic first so that the default bench line carries it
 profile_cfg fp32 gemm hubert_base fp32 32 10 "" 60
 python bench.py > $out/bench_fp32.json 2> $out/bench_fp32.err          # the default run: >= 5 s timed, CPU baseline, other modes
-# 2. BASELINE configs[2] / [3] / [4] exactly as named
-profile_cfg cfg2_hubert_base_b64_bf16 gemm16 hubert_base bf16 64 10 "" 100
-profile_cfg cfg3_hubert_large_bf16 gemm16 hubert_large bf16 32 10 "" 60
-profile_cfg cfg4_wavlm_large_mixed_bf16 gemm16 wavlm_large bf16 32 15 "--mixed" 40
-# 3. the operand modes of the headline workload
+# 2. the in-tolerance throughput mode of the same workload, then BASELINE configs[2] / [3] / [4]: every config's fp16x2 line
+#    (parity < 1e-3) first, its bf16 line (the dtype BASELINE names; parity 1e-2) second
+profile_cfg fp16x2 gemm16 hubert_base fp16x2 32 10 "" 200
 profile_cfg bf16 gemm16 hubert_base bf16 32 10 "" 300
-python bench.py --dtype fp16x2 $Q > $out/bench_fp16x2.json 2>/dev/null
+profile_cfg cfg3_hubert_large_fp16x2 gemm16 hubert_large fp16x2 32 10 "" 40
+profile_cfg cfg4_wavlm_large_mixed_fp16x2 gemm16 wavlm_large fp16x2 32 15 "--mixed" 30
+PROFILE_ONLY_SAVE=${PROFILE_ONLY:-}
+python bench.py --model hubert_base --dtype fp16x2 --batch 64 $Q --steps 100 --warmup 3 > $out/bench_cfg2_hubert_base_b64_fp16x2.json 2>/dev/null
+python bench.py --model hubert_base --dtype bf16 --batch 64 $Q --steps 100 --warmup 3 > $out/bench_cfg2_hubert_base_b64_bf16.json 2>/dev/null
+python bench.py --model hubert_large --dtype bf16 $Q --steps 60 --warmup 2 > $out/bench_cfg3_hubert_large_bf16.json 2>/dev/null
+python bench.py --model wavlm_large --dtype bf16 --secs 15 --mixed $Q --steps 40 --warmup 2 > $out/bench_cfg4_wavlm_large_mixed_bf16.json 2>/dev/null
+# 3. the other operand modes of the headline workload and of configs[1], [3], [4]
 python bench.py --dtype fp32x3 $Q > $out/bench_fp32x3.json 2>/dev/null
 python bench.py --dtype fp16 $Q --steps 200 > $out/bench_fp16.json 2>/dev/null
-# 4. the other modes of configs[1], [3], [4]
 python bench.py --model wav2vec2_base $Q --steps 30 --warmup 2 > $out/bench_cfg1_wav2vec2_base_fp32.json 2>/dev/null
-for d in fp16x2 fp32x3 fp32; do
+for d in fp32x3 fp32; do
   python bench.py --model hubert_large --dtype $d $Q --steps 12 --warmup 1 > $out/bench_cfg3_hubert_large_$d.json 2>/dev/null
   python bench.py --model wavlm_large --dtype $d --secs 15 --mixed $Q --steps 8 --warmup 1 > $out/bench_cfg4_wavlm_large_mixed_$d.json 2>/dev/null
 done
-# 5. micro labs (standalone binaries, seconds each)
-for b in gemm32_lab attn_lab gemm16_lab gemm16_loop_probe; do [ -x tools/micro/$b ] || echo "tools/micro/$b is not built" >&2; done
-tools/micro/gemm32_lab 3 > $out/gemm32_lab_fp32.md 2>&1
-tools/micro/gemm32_lab 3 - x3 > $out/gemm32_lab_x3.md 2>&1
+# 4. micro labs (standalone binaries, seconds each)
+for b in gemm32_lab attn_lab gemm16_lab gemm16_loop_probe mx_probe; do [ -x tools/micro/$b ] || echo "tools/micro/$b is not built" >&2; done
+tools/micro/gemm16_lab cmp 7 8 9 10 > $out/gemm16_lab_modes.md 2>&1        # persistent loop / + store overlap / row-per-lane epilogue / both
+tools/micro/gemm16_lab cmpx 7 9 > $out/gemm16_lab_modes_fp16x2.md 2>&1
+tools/micro/gemm16_lab cmp8 7 > $out/gemm16_lab_shared_panels.md 2>&1       # every operand L2-resident: what the memory side costs
 tools/micro/attn_lab > $out/attn_lab.md 2>&1
-tools/micro/gemm16_lab > $out/gemm16_lab.md 2>&1
-tools/micro/gemm16_lab cmp 1 7 > $out/gemm16_lab_persistent.md 2>&1      # one tile per workgroup against the persistent tile loop
-tools/micro/gemm16_loop_probe > $out/gemm16_loop_probe.md 2>&1
-# 6. parity of every mode against the reference's own outputs
+tools/micro/mx_probe > $out/mx_probe.md 2>&1
+# 5. parity of every mode against the reference's own outputs (synthetic and pretrained-like statistics)
 python tools/parity_table.py > $out/parity.md 2> $out/parity.err
-# 7. a sibling model and the N-rank path, functionally (two ranks share this box's single GPU over a gloo rendezvous)
+# 6. a sibling model and the N-rank path, functionally (two ranks share this box's single GPU over a gloo rendezvous)
 python bench.py --model multires_hubert_base $Q --steps 40 --warmup 3 > $out/bench_multires_hubert_base_fp32.json 2>/dev/null
 python bench.py --gpus 2 --backend gloo --gather layers --steps 5 --warmup 1 --no-profile > $out/bench_2rank_gloo_layers.json 2>/dev/null
+python bench.py --gpus 2 --backend gloo --dtype fp16x2 --exchange-algo direct --steps 5 --warmup 1 --no-profile > $out/bench_2rank_gloo_fp16x2_direct.json 2>/dev/null
 ls $out
