@@ -239,6 +239,8 @@ int s3enc_debug_tap(s3enc_handle h, const char* name, float* host_out, int64_t m
  *                   row-per-lane epilogue (no LDS transpose) wherever it is legal, 3 = chosen by shape (default: 7);
  *   "gemm16_rows":  1 (default) = under mode 7 the GELU epilogues with a 16-bit output (conv1-5, fc1) take the row-per-lane form
  *                   (profiles/r04_gemm16_epilogue.md), 0 = never;
+ *   "conv0_nt":     1 (default) = the fp32 conv0 kernel writes its activation with non-temporal stores, 0 = plain stores;
+ *   "ws_inplace":   1 (default) = post-LN layers run LayerNorm 1 and fc2 in place on one fp32 workspace buffer, 0 = two buffers;
  *   "gelu32":       S3ENC_F32 only: 1 = the one-transcendental erf-GELU every mode uses (default; csrc/common.h gelu_fast: as
  *                   close to an fp64 erf-GELU as 0.5 x (1 + erff(x / sqrt 2)) evaluated in fp32), 0 = libm erff — results
  *                   differ in the last bits. */

@@ -733,6 +733,7 @@ int forward_impl(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
         p.L0 = L[0];
         p.out = actA;
         p.fast = e->x3;
+        p.nt = tuning().conv0_nt;
         Prof pr(e, st, "conv0", 2.0 * B * L[0] * C * p.k0, 4.0 * B * n_max + (double)B * L[0] * C * es);
         HIP_TRY(launch_conv0(dt, p, st));
     }
@@ -1010,10 +1011,13 @@ int forward_impl(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
             ffn_in = xT;
         } else {  // x1 = LN1(y): both the fc1 operand and the FFN residual
             Prof pr(e, st, "layernorm:ln1", 0, gM * D * (8 + (dt == F32 ? 0 : es)));
+            // (ws_inplace: LayerNorm 1 overwrites its input — a wave reads its whole row before it writes — and fc2 then adds its
+            //  product onto that buffer in place: every element is read and written by the same lane)
+            float* x1 = tuning().ws_inplace ? (float*)tmp1 : (float*)tmp2;
             HIP_TRY(launch_layernorm(dt, (const float*)tmp1, (const float*)Lw.ln1g.p, (const float*)Lw.ln1b.p, M, D, 0,
-                                     (float*)tmp2, dt == F32 ? nullptr : xT, st));
-            ffn_res = (const float*)tmp2;
-            ffn_in = dt == F32 ? (const void*)tmp2 : (const void*)xT;
+                                     x1, dt == F32 ? nullptr : xT, st));
+            ffn_res = (const float*)x1;
+            ffn_in = dt == F32 ? (const void*)x1 : (const void*)xT;
         }
         {   // fc1 + bias + GELU
             GemmParams g{};

@@ -275,7 +275,8 @@ __global__ __launch_bounds__(256) void conv0_kernel(Conv0Params p) {
             if (!act[g]) continue;
             const int c0 = chan0(lane, g, coff);
             if constexpr (sizeof(store_t) == 4) {
-                *(float4*)(o + c0) = make_float4(v[g][0], v[g][1], v[g][2], v[g][3]);
+                if (p.nt) __builtin_nontemporal_store((f32x4){v[g][0], v[g][1], v[g][2], v[g][3]}, (f32x4*)(o + c0));
+                else *(float4*)(o + c0) = make_float4(v[g][0], v[g][1], v[g][2], v[g][3]);
             } else {
                 ushort4 h;
                 h.x = Cvt<T>::to(v[g][0]);

@@ -34,6 +34,10 @@ struct Tuning {
     int gemm16_big = 3;    // gemm16.hip: 0 off, 3 = choose by shape, 1 / 2 / 4 / 5 / 6 / 7 = force one configuration
     int gemm16_rows = 1;   // gemm16.hip: 1 = GELU epilogues with a 16-bit output take the row-per-lane (no LDS) form, 0 = never
     int attn_lds_pad = 0;  // 16-bit attention occupancy probe
+    int conv0_nt = 1;      // frontend.hip, fp32 output: 1 = non-temporal row stores (the 2 GB activation streams past the caches:
+                           // 0.578 -> 0.436 ms on HuBERT-base 32 x 10 s, round 4), 0 = plain stores
+    int ws_inplace = 1;    // engine.hip, post-LN layers: 1 = LayerNorm 1 and fc2 work in place on ONE fp32 buffer (49 MB less
+                           // working set per layer: fc2 -3.6 %, LayerNorm -4 % in the bf16 forward, round 4), 0 = two buffers
     int gelu32 = 1;        // S3ENC_F32: 1 = the one-transcendental GELU of every mode (common.h gelu_fast; fp32 rounding level), 0 = libm erff
     int x3_pack_cache = 0; // s3enc_op_gemm(S3ENC_F32X3): keep the packed image of the last weight (micro-benchmarks)
 };
@@ -112,6 +116,7 @@ struct Conv0Params {
     long L0;
     void* out;            // (B, L0, C) compute dtype
     int fast = 0;         // fp32 output with the packed one-transcendental GELU (the split-precision modes)
+    int nt = 0;           // fp32 output: non-temporal stores
 };
 hipError_t launch_conv0(int dtype, const Conv0Params& p, hipStream_t s);
 

@@ -16,7 +16,8 @@ int tuning_set(Tuning& t, const char* key, int value, const char** err) {
         {"gemm_variant", &Tuning::gemm_variant, 0, 63},      {"gemm_lds_pad", &Tuning::gemm_lds_pad, 0, 120 * 1024},
         {"gemm32_big", &Tuning::gemm32_big, 0, 5},           {"gemm_x3_tile", &Tuning::gemm_x3_tile, 0, 5},
         {"gemm16_big", &Tuning::gemm16_big, 0, 10},          {"gemm16_rows", &Tuning::gemm16_rows, 0, 1},
-        {"attn_lds_pad", &Tuning::attn_lds_pad, 0, 48 * 1024},
+        {"attn_lds_pad", &Tuning::attn_lds_pad, 0, 48 * 1024}, {"conv0_nt", &Tuning::conv0_nt, 0, 1},
+        {"ws_inplace", &Tuning::ws_inplace, 0, 1},
         {"x3_pack_cache", &Tuning::x3_pack_cache, 0, 1},     {"gelu32", &Tuning::gelu32, 0, 1},
     };
     static thread_local char msg[160];
