@@ -71,3 +71,34 @@ def test_stale_traffic_record_is_not_quoted(tmp_path):
     got, note = bench.pmc_traffic(str(path), "hubert_base", "fp32", 32, 10.0)
     assert got["gemm_bytes_per_launch"] == 123 and note is None
     assert bench.pmc_traffic(str(path), "hubert_large", "fp32", 32, 10.0) == (None, None)
+
+
+def test_fp16_error_budget_tool_runs_on_a_tiny_fixture():
+    """tools/fp16_error_budget.py (the float64 emulation behind DESIGN §5's choice of fp32 operands in the fp16x2 mode): every
+    site's own contribution is below the all-sites total, and exact conv activations lower it on a GroupNorm extractor."""
+    import re
+
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fp16_error_budget.py"), "tiny_hubert_pl"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rows = dict(re.findall(r"\| (.+?) \| ([0-9.e+-]+) \|", out.stdout))
+    total = float(rows["every site"])
+    assert 1e-4 < total < 5e-3
+    for site in ("conv", "feat", "ln_out", "attn_out", "fc1_out"):
+        assert float(rows[f"only `{site}`"]) <= total * 1.05
+    assert float(rows["every site but `conv`"]) < total
+
+
+def test_scale_curve_summary_table(tmp_path):
+    """tools/scale_curve.sh ends with a python summary over the bench lines it collected: run that part on fabricated lines."""
+    import re
+
+    script = open(os.path.join(ROOT, "tools", "scale_curve.sh")).read()
+    body = re.search(r"<<'PY'\n(.*?)\nPY\n", script, re.S).group(1)
+    for name, n, v in (("weak_fp32_n1", 1, 440000.0), ("weak_fp32_n2_ring", 2, 860000.0), ("weak_fp32_n2_direct", 2, 870000.0)):
+        line = {"n_gpus": n, "value": v, "ms_per_step": 36.0,
+                "comm": {"exposed_ms_per_step": 0.4, "bytes_received_per_gpu_per_step": 123} if n > 1 else None}
+        (tmp_path / f"{name}.json").write_text(json.dumps(line) + "\n")
+    out = subprocess.run([sys.executable, "-c", body, str(tmp_path)], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr
+    assert "| weak_fp32_n2_direct | 2 | 870000 | 36.0 | 1.98 |" in out.stdout and "weak_fp32_n1" in out.stdout
