@@ -202,7 +202,7 @@ class LegacyFeaturizer(nn.Module):
             self.layer_num = len(feature)
             print(f"[{self.name}] - Take a list of {self.layer_num} features and weighted sum them.", file=sys.stderr)
             self.weights = nn.Parameter(torch.zeros(self.layer_num))
-            feature = self._weighted_sum(list(feature))
+            feature = self._weighted_sum(list(feature), probe=True)  # (shape probe only: plain torch, like the reference)
         self.output_dim = feature.size(-1)
         if hasattr(upstream, "get_downsample_rates"):
             self.downsample_rate = upstream.get_downsample_rates(feature_selection)
@@ -222,7 +222,7 @@ class LegacyFeaturizer(nn.Module):
                 return feature[self.layer_selection]
         return feature
 
-    def _weighted_sum(self, feature: List[torch.Tensor]) -> torch.Tensor:
+    def _weighted_sum(self, feature: List[torch.Tensor], probe: bool = False) -> torch.Tensor:
         assert self.layer_num == len(feature), (
             f"the upstream returned {len(feature)} states, the weights were built for {self.layer_num} (an upstream with "
             "layer drop returns a varying number of states: select one layer instead, e.g. last_hidden_state)")
@@ -230,7 +230,7 @@ class LegacyFeaturizer(nn.Module):
         # the library's weighted sum (and, for training, its backward for the LAYER WEIGHTS) when the states are GPU-resident
         # constants; states that carry a graph (a trainable upstream: the reference's `upstream_trainable` flow) need the
         # gradient with respect to the states too, which only the torch form below propagates
-        if feature[0].is_cuda and not any(f.requires_grad for f in feature):
+        if feature[0].is_cuda and not probe and not any(f.requires_grad for f in feature):
             return _WeightedSum.apply(norm_weights, self.normalize, *feature)
         stacked = torch.stack([f.float() for f in feature], dim=0)
         if self.normalize:
