@@ -11,5 +11,6 @@ $H tools/micro/gemm16_loop_probe.hip -o tools/micro/gemm16_loop_probe
 $H tools/micro/gemm_loop_probe.hip -o tools/micro/gemm_loop_probe
 $H tools/micro/mfma_peak.hip -o tools/micro/mfma_peak
 $H tools/micro/mx_probe.hip -o tools/micro/mx_probe
+$H tools/micro/mx_gemm_lab.hip -o tools/micro/mx_gemm_lab
 hipcc -O2 --offload-arch=gfx950 tools/micro/gemm32_lab.cpp -Iinclude -Ls3prl_amd -ls3enc -Wl,-rpath,'$ORIGIN/../../s3prl_amd' -o tools/micro/gemm32_lab
 ls -la tools/micro | grep -v "\.hip\|\.cpp\|\.sh"
