@@ -226,6 +226,8 @@ class LegacyFeaturizer(nn.Module):
         assert self.layer_num == len(feature), (
             f"the upstream returned {len(feature)} states, the weights were built for {self.layer_num} (an upstream with "
             "layer drop returns a varying number of states: select one layer instead, e.g. last_hidden_state)")
+        if probe:  # construction-time shape probe: on the CPU, where the freshly created weights live (as the reference does)
+            feature = [f.detach().cpu() for f in feature]
         norm_weights = F.softmax(self.weights, dim=-1)
         # the library's weighted sum (and, for training, its backward for the LAYER WEIGHTS) when the states are GPU-resident
         # constants; states that carry a graph (a trainable upstream: the reference's `upstream_trainable` flow) need the
@@ -235,7 +237,7 @@ class LegacyFeaturizer(nn.Module):
         stacked = torch.stack([f.float() for f in feature], dim=0)
         if self.normalize:
             stacked = F.layer_norm(stacked, stacked.shape[-1:])
-        return torch.tensordot(norm_weights.to(stacked.dtype), stacked, dims=1)
+        return torch.tensordot(norm_weights.to(device=stacked.device, dtype=stacked.dtype), stacked, dims=1)
 
     def tolist(self, paired_wavs: List[torch.Tensor], paired_feature: torch.Tensor) -> List[torch.Tensor]:
         assert paired_feature.dim() == 3, "(batch_size, max_seq_len, feat_dim)"
