@@ -36,9 +36,15 @@ struct P {
     int M, N, K, store;
 };
 
-template <bool MX>
+// MODE 0: two fp16 terms; 1: MX second term, A image staged from memory (a producer wrote it); 2: MX second term, the A image is
+// built IN the kernel from the fp16 fragments the lane already holds (block max, scale, 16 converts per 32 values) — no producer,
+// no A-side staging.  The fragment of step q of lane (row, half) is the 16-byte slot 4 half + q of the row's 128-byte K step, i.e.
+// k = 32 half + 8 q + j: the lane's 32 values over the four steps ARE block `half` in natural order, so W_lo needs no re-packing.
+template <int MODE>
 __global__ __launch_bounds__(NTHR, 2) void gemm(P p) {
-    constexpr int STAGE = A16 + W16 + (MX ? A4B + W4B : 0);
+    constexpr bool MX = MODE != 0, CONV = MODE == 2;
+    constexpr int STAGE = A16 + W16 + (MX ? (CONV ? 0 : A4B) + W4B : 0);
+    constexpr int OFF_W4 = A16 + W16 + (CONV ? 0 : A4B);
     constexpr int SCB = (BM + BN) * 4;  // scale bytes per buffer: 4 blocks (= 2 K steps) per row
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 2, wc = wave & 3, half = lane >> 5, l31 = lane & 31;
@@ -100,8 +106,8 @@ __global__ __launch_bounds__(NTHR, 2) void gemm(P p) {
 #pragma unroll
         for (int pc = 0; pc < NLB; ++pc) dma16(w_ptr[pc] + kb, sa + A16 + pc * PASS);
         if (MX) {
-            if (wave < BM / 32) dma16(a4_ptr + (long)kt * 32, sa + A16 + W16);          // 2 lanes per row: BM rows = BM / 32 waves
-            dma16(w4_ptr + (long)kt * 32, sa + A16 + W16 + A4B);
+            if (!CONV && wave < BM / 32) dma16(a4_ptr + (long)kt * 32, sa + A16 + W16);  // 2 lanes per row: BM rows = BM / 32 waves
+            dma16(w4_ptr + (long)kt * 32, sa + OFF_W4);
             if (!(kt & 1) && wave < (BM + BN) / 64) dma4(sc_ptr + 2 * kt, lds_sc + ((kt >> 1) & 1) * SCB);  // blocks 2 kt .. 2 kt + 3
         }
     };
@@ -124,6 +130,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm(P p) {
     barrier_all();
     for (int kt = 0; kt < nk; ++kt) {
         const char* st = smem + (kt & 1) * STAGE;
+        uint4 keep[CONV ? MI : 1][4];  // CONV: the lane's 32 values of each row block (4 q steps x 8 halves)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int so = ((half * 4 + q) ^ swz) << 4;
@@ -134,10 +141,12 @@ __global__ __launch_bounds__(NTHR, 2) void gemm(P p) {
             for (int i = 0; i < MI; ++i) fa[i] = *(const uint4*)(st + a_row0 + i * 32 * ROWB + so);
             if (q == 0 && kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
+            for (int i = 0; i < MI; ++i) {
+                if constexpr (CONV) keep[i][q] = fa[i];
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[i]), __builtin_bit_cast(f16x8, fb[j]), acc[i][j], 0, 0, 0);
+            }
         }
         if (MX) {
             const char* sc = smem + 2 * STAGE + ((kt >> 1) & 1) * SCB + (kt & 1) * 2 + half;
@@ -146,13 +155,46 @@ __global__ __launch_bounds__(NTHR, 2) void gemm(P p) {
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
                 const int row = wr * WTM + i * 32 + l31;
-                a4[i] = *(const uint4*)(st + A16 + W16 + row * 32 + half * 16);
-                sa[i] = (int)(*(const uint8_t*)(sc + row * 4)) * 0x01010101;
+                if constexpr (CONV) {
+                    // block max of the 32 halves (|x| as bit patterns: positive fp16 order like unsigned integers), scale 2^e with
+                    // max / 2^e <= 6, sixteen pair conversions
+                    unsigned mx = 0;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const unsigned d[4] = {keep[i][q].x, keep[i][q].y, keep[i][q].z, keep[i][q].w};
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const unsigned a = d[c] & 0x7fff7fffu;
+                            mx = max(mx, max(a & 0xffffu, a >> 16));
+                        }
+                    }
+                    const float amax = (float)__builtin_bit_cast(_Float16, (unsigned short)mx);
+                    int ex = amax > 0.f ? __builtin_amdgcn_frexp_expf(amax * (1.f / 6.f)) : -127;
+                    ex = ex < -127 ? -127 : ex;
+                    const float scf = __builtin_amdgcn_ldexpf(1.f, ex);
+                    unsigned o[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {  // elements 8 q .. 8 q + 7 -> dword q
+                        const h2 v0 = __builtin_bit_cast(h2, keep[i][q].x), v1 = __builtin_bit_cast(h2, keep[i][q].y);
+                        const h2 v2 = __builtin_bit_cast(h2, keep[i][q].z), v3 = __builtin_bit_cast(h2, keep[i][q].w);
+                        unsigned w_ = 0;
+                        w_ = __builtin_amdgcn_cvt_scalef32_pk_fp4_f16(w_, v0, scf, 0);
+                        w_ = __builtin_amdgcn_cvt_scalef32_pk_fp4_f16(w_, v1, scf, 1);
+                        w_ = __builtin_amdgcn_cvt_scalef32_pk_fp4_f16(w_, v2, scf, 2);
+                        w_ = __builtin_amdgcn_cvt_scalef32_pk_fp4_f16(w_, v3, scf, 3);
+                        o[q] = w_;
+                    }
+                    a4[i] = make_uint4(o[0], o[1], o[2], o[3]);
+                    sa[i] = (ex + 127) * 0x01010101;
+                } else {
+                    a4[i] = *(const uint4*)(st + A16 + W16 + row * 32 + half * 16);
+                    sa[i] = (int)(*(const uint8_t*)(sc + row * 4)) * 0x01010101;
+                }
             }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int row = wc * 64 + j * 32 + l31;
-                b4[j] = *(const uint4*)(st + A16 + W16 + A4B + row * 32 + half * 16);
+                b4[j] = *(const uint4*)(st + OFF_W4 + row * 32 + half * 16);
                 sb[j] = (int)(*(const uint8_t*)(sc + (BM + row) * 4)) * 0x01010101;
             }
 #pragma unroll
@@ -193,7 +235,10 @@ __global__ void mx_pack(const _Float16* x, long rows, int K, uint4* data, uint8_
     const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
     const int kblocks = K / 32;
     if (idx >= rows * kblocks) return;
-    const _Float16* src = x + (idx / kblocks) * K + (idx % kblocks) * 32;
+    const int blk = (int)(idx % kblocks);
+    const _Float16* row = x + (idx / kblocks) * K;
+    _Float16 src[32];
+    for (int e = 0; e < 32; ++e) src[e] = row[32 * blk + e];
     float amax = 0.f;
     for (int e = 0; e < 32; ++e) amax = fmaxf(amax, fabsf((float)src[e]));
     int ex = amax > 0.f ? (int)ceilf(log2f(amax / 6.f)) : -127;
@@ -281,16 +326,20 @@ static void release(Dev& d) {
     for (void* q : {(void*)d.A, (void*)d.W2, (void*)d.Whi, (void*)d.Wlo16, (void*)d.A4, (void*)d.W4, (void*)d.A4s, (void*)d.W4s, (void*)d.C, (void*)d.Wf}) (void)hipFree(q);
 }
 
-template <bool MX>
-static int launch(const Dev& d, int M, int N, int K, int store, const char* w_override = nullptr) {
-    constexpr int STAGE = A16 + W16 + (MX ? A4B + W4B : 0);
+template <int MODE>
+static int launch(const Dev& d, int M, int N, int K, int store) {
+    constexpr bool MX = MODE != 0, CONV = MODE == 2;
+    constexpr int STAGE = A16 + W16 + (MX ? (CONV ? 0 : A4B) + W4B : 0);
     const int lds = 2 * STAGE + (MX ? 2 * (BM + BN) * 4 : 0);
     static bool set = false;
-    if (!set) { CK(hipFuncSetAttribute((const void*)gemm<MX>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); set = true; }
-    P p{d.A, w_override ? w_override : (MX ? d.Whi : d.W2), d.A4, d.A4s, d.W4, d.W4s, d.C, M, N, K, store};
+    if (!set) { CK(hipFuncSetAttribute((const void*)gemm<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); set = true; }
+    P p{d.A, MX ? d.Whi : d.W2, d.A4, d.A4s, d.W4, d.W4s, d.C, M, N, K, store};
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-    hipLaunchKernelGGL(gemm<MX>, dim3(tiles), dim3(NTHR), lds, 0, p);
+    hipLaunchKernelGGL(gemm<MODE>, dim3(tiles), dim3(NTHR), lds, 0, p);
     return 0;
+}
+static int launch_mode(int mode, const Dev& d, int M, int N, int K, int store) {
+    return mode == 0 ? launch<0>(d, M, N, K, store) : mode == 1 ? launch<1>(d, M, N, K, store) : launch<2>(d, M, N, K, store);
 }
 
 int main() {
@@ -321,14 +370,14 @@ int main() {
         };
         printf("\n## relative error of the product against float64 (M = %d, N = %d, K = %d; outlier activation channels, heavy-tailed weights)\n\n", M, N, K);
         printf("| weights | error vs A x W | error vs A x fp16(W) |\n|---|---:|---:|\n");
-        CK(hipMemset(d.C, 0xff, c.size() * 4));
-        if (launch<false>(d, M, N, K, 1)) return 1;
-        CK(hipMemcpy(c.data(), d.C, c.size() * 4, hipMemcpyDeviceToHost));
-        printf("| two fp16 terms (K loop over 2K) | %.3e | %.3e |\n", err(ref), err(ref_hi));
-        CK(hipMemset(d.C, 0xff, c.size() * 4));
-        if (launch<true>(d, M, N, K, 1)) return 1;
-        CK(hipMemcpy(c.data(), d.C, c.size() * 4, hipMemcpyDeviceToHost));
-        printf("| fp16 + MX-fp4 second term | %.3e | %.3e |\n", err(ref), err(ref_hi));
+        const char* vn[3] = {"two fp16 terms (K loop over 2K)", "fp16 + MX-fp4 second term, A image staged (a producer wrote it)",
+                             "fp16 + MX-fp4 second term, A image built in the kernel from the fp16 fragments"};
+        for (int mode = 0; mode < 3; ++mode) {
+            CK(hipMemset(d.C, 0xff, c.size() * 4));
+            if (launch_mode(mode, d, M, N, K, 1)) return 1;
+            CK(hipMemcpy(c.data(), d.C, c.size() * 4, hipMemcpyDeviceToHost));
+            printf("| %s | %.3e | %.3e |\n", vn[mode], err(ref), err(ref_hi));
+        }
         {   // one term: the fp16 error floor of the weights (host)
             double e = 0;
             for (size_t i = 0; i < ref.size(); ++i) e += (ref_hi[i] - ref[i]) * (ref_hi[i] - ref[i]);
@@ -342,19 +391,21 @@ int main() {
                                 {"conv1-like 127984x512x1536", 127984, 512, 1536}, {"L.fc1 15968x4096x1024", 15968, 4096, 1024}};
         hipEvent_t e0, e1;
         CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-        printf("\n## time per launch, us (algorithmic TFLOP/s = 2 M N K / t), K loop only (no stores) | with the plain fp32 epilogue\n\n");
-        printf("| shape | two fp16 terms | fp16 + MX-fp4 | speed-up | two fp16 terms, stores | fp16 + MX-fp4, stores | speed-up |\n|---|---:|---:|---:|---:|---:|---:|\n");
+        printf("\n## time per launch, us (algorithmic TFLOP/s = 2 M N K / t): K loop only (no stores) | with the plain fp32 epilogue\n\n");
+        printf("| shape | two fp16 terms | MX, A image staged | speed-up | MX, A image built in the kernel | speed-up | two terms, stores | MX staged, stores | speed-up | MX in-kernel, stores | speed-up |\n"
+               "|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|\n");
         for (const Shape& sh : shapes) {
             Dev d;
             if (setup(sh.M, sh.N, sh.K, d, nullptr, nullptr, 7)) return 1;
-            double t[2][2] = {{1e30, 1e30}, {1e30, 1e30}};
+            double t[2][3];
+            for (auto& row : t) for (double& v : row) v = 1e30;
             for (int store = 0; store < 2; ++store)
-                for (int r = 0; r < 4; ++r)
-                    for (int v = 0; v < 2; ++v) {
-                        if (v ? launch<true>(d, sh.M, sh.N, sh.K, store) : launch<false>(d, sh.M, sh.N, sh.K, store)) return 1;
+                for (int r = 0; r < 3; ++r)
+                    for (int v = 0; v < 3; ++v) {
+                        if (launch_mode(v, d, sh.M, sh.N, sh.K, store)) return 1;
                         CK(hipEventRecord(e0, 0));
                         for (int k = 0; k < 20; ++k)
-                            if (v ? launch<true>(d, sh.M, sh.N, sh.K, store) : launch<false>(d, sh.M, sh.N, sh.K, store)) return 1;
+                            if (launch_mode(v, d, sh.M, sh.N, sh.K, store)) return 1;
                         CK(hipEventRecord(e1, 0));
                         CK(hipEventSynchronize(e1));
                         float ms;
@@ -362,8 +413,12 @@ int main() {
                         if (r && ms / 20 < t[store][v]) t[store][v] = ms / 20;
                     }
             const double fl = 2.0 * sh.M * (double)sh.N * sh.K;
-            printf("| %s | %.1f (%.0f) | %.1f (%.0f) | %.2f | %.1f (%.0f) | %.1f (%.0f) | %.2f |\n", sh.name, t[0][0] * 1e3, fl / t[0][0] * 1e-9, t[0][1] * 1e3,
-                   fl / t[0][1] * 1e-9, t[0][0] / t[0][1], t[1][0] * 1e3, fl / t[1][0] * 1e-9, t[1][1] * 1e3, fl / t[1][1] * 1e-9, t[1][0] / t[1][1]);
+            printf("| %s |", sh.name);
+            for (int store = 0; store < 2; ++store) {
+                printf(" %.1f (%.0f) |", t[store][0] * 1e3, fl / t[store][0] * 1e-9);
+                for (int v = 1; v < 3; ++v) printf(" %.1f (%.0f) | %.2f |", t[store][v] * 1e3, fl / t[store][v] * 1e-9, t[store][0] / t[store][v]);
+            }
+            printf("\n");
             fflush(stdout);
             release(d);
         }
