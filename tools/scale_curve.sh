@@ -1,7 +1,7 @@
 #!/bin/bash
-# The first 8-GPU lease, made decisive (run on a node with >= 8 MI355X; ~8-10 minutes):
-#   weak scaling of the metric's workload (HuBERT-base, 32 x 10 s per GPU) and strong scaling of cfg4 (WavLM-large, 256 x <= 15 s
-#   mixed over all GPUs), for the exact mode (fp32) and the in-tolerance throughput mode (fp16x2), at N = 1, 2, 4, 8, with BOTH
+# The first 8-GPU lease, made decisive (run on a node with >= 8 MI355X; 24 bench runs of 15-30 s: ~10 minutes):
+#   weak scaling of the metric's workload (HuBERT-base, 32 x 10 s per GPU) in the exact mode (fp32) and the in-tolerance throughput
+#   mode (fp16x2), strong scaling of cfg4 (WavLM-large, 256 x <= 15 s mixed over all GPUs) in fp16x2, at N = 1, 2, 4, 8, with BOTH
 #   forms of the exchange (ring = one RCCL all-gather per state; direct = all-pairs send / receive, one peer per xGMI link) and the
 #   two ways of issuing it (torch.distributed / the library's own s3enc_comm_* entry points).
 # Every line is bench.py's JSON (value = whole-job frames/s, comm.exposed_ms_per_step = what the compute does not hide); the
@@ -22,21 +22,20 @@ run() {  # name, N, bench flags...
 }
 
 for n in $ns; do
-  for dt in fp32 fp16x2; do
-    steps=$([ $dt = fp32 ] && echo 40 || echo 100)
-    if [ $n -eq 1 ]; then
-      run weak_${dt}_n1 1 --dtype $dt --steps $steps --warmup 5
-      run strong_${dt}_n1 1 --model wavlm_large --secs 15 --mixed --scaling strong --global-batch 256 --dtype $dt --steps 3 --warmup 1
-      continue
-    fi
-    for algo in ring direct; do
-      run weak_${dt}_n${n}_${algo} $n --dtype $dt --steps $steps --warmup 5 --exchange-algo $algo
-      run strong_${dt}_n${n}_${algo} $n --model wavlm_large --secs 15 --mixed --scaling strong --global-batch 256 --dtype $dt \
-          --steps $((3 * n)) --warmup 2 --exchange-algo $algo
-    done
+  if [ $n -eq 1 ]; then
+    run weak_fp32_n1 1 --dtype fp32 --steps 40 --warmup 5
+    run weak_fp16x2_n1 1 --dtype fp16x2 --steps 100 --warmup 5
+    run strong_fp16x2_n1 1 --model wavlm_large --secs 15 --mixed --scaling strong --global-batch 256 --dtype fp16x2 --steps 3 --warmup 1
+    continue
+  fi
+  for algo in ring direct; do
+    run weak_fp32_n${n}_${algo} $n --dtype fp32 --steps 40 --warmup 5 --exchange-algo $algo
+    run weak_fp16x2_n${n}_${algo} $n --dtype fp16x2 --steps 100 --warmup 5 --exchange-algo $algo
+    run strong_fp16x2_n${n}_${algo} $n --model wavlm_large --secs 15 --mixed --scaling strong --global-batch 256 --dtype fp16x2 \
+        --steps $((3 * n)) --warmup 2 --exchange-algo $algo
   done
-  [ $n -gt 1 ] || continue
-  # the exchange behind the C ABI (what a non-Python binder runs), the featurized form (13x / 25x fewer bytes), and no exchange
+  [ $n -eq $maxn ] || continue
+  # at the full node only: the exchange behind the C ABI (what a non-Python binder runs), the featurized form (13x fewer bytes), none
   run weak_fp16x2_n${n}_direct_cabi $n --dtype fp16x2 --steps 100 --warmup 5 --exchange-algo direct --exchange-via cabi
   run weak_fp16x2_n${n}_featurized $n --dtype fp16x2 --steps 100 --warmup 5 --gather featurized
   run weak_fp16x2_n${n}_none $n --dtype fp16x2 --steps 100 --warmup 5 --gather none
