@@ -672,7 +672,9 @@ int forward_impl(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
     void *actA, *actB, *tmp32, *feat32, *featT, *x32, *xpc, *xT, *qkv, *attn, *tmp1, *tmp2, *hbuf, *gate, *ffnbuf;
     for (int pass = 0; pass < 2; ++pass) {
         Bump wb(pass ? e->ws.p : nullptr);
-        actA = wb.take((size_t)B * L[0] * C * es);
+        // conv0's output in the compute dtype; in the fp16x2 hybrid conv2, conv4, ... write fp32 rows back here: L[2] <= L[0] / 2
+        // only when conv1 * conv2 stride >= 2, which no config validation promises
+        actA = wb.take(std::max((size_t)B * L[0] * C * es, (e->x2_conv_f32_from && c.n_conv > 2) ? (size_t)B * L[2] * C * 4 : (size_t)0));
         actB = wb.take((size_t)B * L[1] * C * (e->x2_conv_f32_from ? 4 : es));  // (fp32 activations between the later convs)
         tmp32 = lnmode ? wb.take((size_t)B * L[1] * C * 4) : nullptr;
         feat32 = featln ? wb.take((size_t)M * C * 4) : nullptr;

@@ -12,7 +12,7 @@
 
 Differences from the reference, all on the cheap side: no probe forward at construction when the expert can answer from its
 checkpoint config (layer count / hidden size / stride), and the per-layer ``F.layer_norm`` of ``normalize=True`` is done by the
-library where it can be (fused path).
+library: as part of the fused epilogue, or (un-fused ``S3PRLUpstream``) by its row kernel through ``s3enc_op_layernorm``.
 """
 
 from __future__ import annotations
@@ -48,6 +48,34 @@ def _fit_frames(h: torch.Tensor, frames: int) -> torch.Tensor:
         return h
     assert 2 * min(n, frames) > max(n, frames), f"upstream returned {n} frames where {frames} were expected"
     return h[:, torch.arange(frames, device=h.device).clamp_(max=n - 1), :]
+
+
+_LN_AFFINE: Dict[tuple, tuple] = {}  # (device index, C) -> (ones, zeros): the library's row kernel takes gamma / beta
+
+
+def _state_layer_norm(h: torch.Tensor) -> torch.Tensor:
+    """``F.layer_norm(h, h.shape[-1:])`` of one state (nn/upstream.py:224-225).  GPU-resident fp32 constants go through the
+    library's row kernel (``s3enc_op_layernorm``: one wave per row, the kernel every LayerNorm of the encoder runs on);
+    anything else (CPU states of a probe forward, states that carry a graph) keeps the torch op."""
+    C = h.shape[-1]
+    if not (h.is_cuda and h.dtype == torch.float32 and not h.requires_grad and C % 4 == 0 and C <= 2048):
+        return F.layer_norm(h, h.shape[-1:])
+    from . import _lib
+
+    x = h.contiguous()
+    if x.data_ptr() % 16:
+        return F.layer_norm(h, h.shape[-1:])
+    key = (x.device.index, C)
+    if key not in _LN_AFFINE:
+        _LN_AFFINE[key] = (torch.ones(C, device=x.device), torch.zeros(C, device=x.device))
+    gamma, beta = _LN_AFFINE[key]
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().s3enc_op_layernorm(_lib.DTYPES["fp32"], x.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                            x.numel() // C, C, 0, out.data_ptr(), None,
+                                            torch.cuda.current_stream(x.device).cuda_stream)
+    _lib.check(rc, "s3enc_op_layernorm")
+    return out
 
 
 def _split_batch(wavs: torch.Tensor, wavs_len: torch.Tensor):
@@ -128,7 +156,7 @@ class S3PRLUpstream(nn.Module):
         for h, stride in zip(states, self.downsample_rates):
             h_len = _frames(given_len, stride)
             h = _fit_frames(h, _frames(padded, stride))[:, : int(h_len.max()), :]
-            all_hs.append(F.layer_norm(h, h.shape[-1:]) if self.normalize else h)
+            all_hs.append(_state_layer_norm(h) if self.normalize else h)
             all_lens.append(h_len)
         return all_hs, all_lens
 

@@ -154,7 +154,8 @@ def _pretrained_like(cfg: EncoderConfig, w: Dict[str, np.ndarray], seed: int) ->
                 v[hot] *= rng.uniform(30.0, 100.0, size=(len(hot), 1)) if pre_ln else rng.uniform(8.0, 20.0, size=(len(hot), 1))
             if name.endswith((".fc1.weight", "q_proj.weight", "k_proj.weight", "v_proj.weight")):
                 # ... and its readers have learned small weights on them and on the high-gain channels (otherwise every
-                # logit saturates and fp32 itself is 1e-3 away from an fp64 evaluation: tools/profile_conditioning.py)
+                # logit saturates and fp32 itself is 1e-3 away from an fp64 evaluation: the "ref vs fp64" column of
+                # tools/parity_table.py / profiles/r04_parity.md is the check that a profile stays well-conditioned)
                 v[:, hot] *= 0.05 if pre_ln else 0.1
                 v[:, warm] *= 0.3
         elif "conv_layers" in name and leaf == "weight" and v.ndim == 3:

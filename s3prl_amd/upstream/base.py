@@ -10,7 +10,11 @@ Contract kept from the reference (upstream/example/expert.py:11-77,
   adds them (interfaces.py:119-129).  Because the dict is complete, this module registers NO hooks;
 * ``get_downsample_rates(key) -> 320``.
 
-The forward is inference-only (the HIP path has no backward): asking for gradients raises.  Waveforms on the CPU are
+The forward is inference-only (the HIP path has no backward): asking for gradients raises — for waveforms that require
+grad at the call, and for the reference's fine-tuning flow (``upstream_trainable``: ``entry.model.train()`` + a forward
+with autograd enabled, downstream/runner.py:258-262,296-301) at ``loss.backward()``: in training mode the states carry an
+autograd node whose backward raises, so an expert that has no parameters is never silently "fine-tuned" as a frozen
+one.  Frozen use (``.eval()`` or ``torch.no_grad()``) is unaffected.  Waveforms on the CPU are
 copied to the current GPU, encoded there, and the states are returned on the waveforms' device (that is a transfer,
 not a fallback: without a GPU the call raises) — ``S3PRLUpstream.__init__`` probes every upstream with CPU pseudo
 waveforms (nn/upstream.py:124-126).
@@ -26,6 +30,22 @@ import torch
 from ..ckpt import load_checkpoint
 from ..config import EncoderConfig
 from ..encoder import HipEncoder
+
+
+class _NoBackward(torch.autograd.Function):
+    """Identity whose backward refuses: marks the states of a training-mode forward (see the module docstring)."""
+
+    @staticmethod
+    def forward(ctx, states, anchor):
+        return states.view_as(states)
+
+    @staticmethod
+    def backward(ctx, grad):
+        raise RuntimeError(
+            "s3prl_amd upstream experts are inference-only: a gradient reached the hidden states of a training-mode "
+            "forward (the reference's `upstream_trainable` / fine-tuning flow), but the HIP encoder has no backward and "
+            "the expert holds no parameters — it would be silently frozen.  Freeze it explicitly (`.eval()` or "
+            "`torch.no_grad()` around the upstream) or fine-tune with the reference s3prl expert")
 
 
 class HipUpstreamExpert(torch.nn.Module):
@@ -105,19 +125,24 @@ class HipUpstreamExpert(torch.nn.Module):
         if torch.is_grad_enabled() and any(w.requires_grad for w in wavs):
             raise RuntimeError("s3prl_amd upstream experts are inference-only (no backward through the HIP encoder)")
 
+    def _guard_backward(self, states: torch.Tensor) -> torch.Tensor:
+        if self.training and torch.is_grad_enabled():
+            return _NoBackward.apply(states, torch.zeros(0, device=states.device, requires_grad=True))
+        return states
+
     def encode(self, wavs: List[torch.Tensor], n_max: int = None, selection: Optional[str] = None,
                out_dtype: Optional[str] = None) -> torch.Tensor:
         """(NS, B, T, D) on the compute GPU.  ``n_max``: global pad-to length for data-parallel shards."""
         self._check_inference(wavs)
-        return self._encoder_for(self._compute_device(wavs)).forward(wavs, n_max=n_max, selection=selection,
-                                                                     out_dtype=out_dtype)
+        return self._guard_backward(self._encoder_for(self._compute_device(wavs)).forward(
+            wavs, n_max=n_max, selection=selection, out_dtype=out_dtype))
 
     def encode_featurized(self, wavs: List[torch.Tensor], weights, normalize: bool = False, n_max: int = None,
                           selection: Optional[str] = None) -> torch.Tensor:
         """(B, T, D) fp32: the Featurizer's weighted sum computed as the encoder's epilogue (no per-layer slab)."""
         self._check_inference(wavs)
-        return self._encoder_for(self._compute_device(wavs)).forward_featurized(wavs, weights, normalize, n_max=n_max,
-                                                                                selection=selection)
+        return self._guard_backward(self._encoder_for(self._compute_device(wavs)).forward_featurized(
+            wavs, weights, normalize, n_max=n_max, selection=selection))
 
     def _result(self, hs: torch.Tensor, wav_device: torch.device, full: bool = True):
         if hs.device != wav_device:

@@ -1,8 +1,11 @@
-"""hub entries in the reference's naming (s3prl/upstream/distiller/hubconf.py:13-46).  No network in this build: the
-URL-backed names need ``ckpt=`` pointing at a local file."""
+"""hub entries of DistilHuBERT under the reference's names and signatures (s3prl/upstream/distiller/hubconf.py:13-46):
+``distiller_local`` / ``distiller_url`` and the released ``distilhubert`` / ``distilhubert_base``.  URLs resolve to the
+reference's cache file (``s3prl_amd.download``)."""
 
 import os
 
+from ...download import urls_to_filepaths as _urls_to_filepaths
+from .. import _released
 from .expert import UpstreamExpert as _UpstreamExpert
 
 
@@ -13,15 +16,11 @@ def distiller_local(ckpt, *args, **kwargs):
 
 def distiller_url(ckpt, refresh=False, *args, **kwargs):
     if str(ckpt).startswith("http"):
-        raise RuntimeError(f"distiller: no network in this build, cannot fetch {ckpt} — pass a local checkpoint path")
+        ckpt = _urls_to_filepaths(str(ckpt), refresh=refresh)
     return distiller_local(ckpt, *args, **kwargs)
 
 
-def distilhubert(refresh=False, *args, **kwargs):
-    return distilhubert_base(refresh=refresh, *args, **kwargs)
-
-
-def distilhubert_base(refresh=False, *args, **kwargs):
-    if "ckpt" not in kwargs and not args:
-        raise RuntimeError("distilhubert: no network in this build — pass ckpt=<checkpoint> (see distiller_local)")
-    return distiller_local(*args, **kwargs)
+distilhubert = _released.alias("distilhubert", lambda: distilhubert_base, "DistilHuBERT (distiller/hubconf.py:31-35)")
+distilhubert_base = _released.positional(
+    "distilhubert_base", distiller_url,
+    "https://huggingface.co/leo19941227/distilhubert/resolve/main/distilhubert_ls960_4-8-12.ckpt")

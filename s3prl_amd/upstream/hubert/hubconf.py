@@ -1,12 +1,19 @@
-"""hub entries in the reference's naming convention (s3prl/upstream/hubert/hubconf.py:29-75): ``hubert_custom(ckpt,
-legacy=False, fairseq=False, refresh=False, **kwargs)`` and its aliases ``hubert_local`` / ``hubert_url``.  This build has
-no network: ``http`` sources raise; ``fairseq=True`` reads the fairseq checkpoint layout directly (``s3prl_amd.ckpt``);
-``legacy=True`` (the reference's LegacyUpstreamExpert imports the ``fairseq`` package itself) raises."""
+"""hub entries of the HuBERT family under the reference's names and signatures (s3prl/upstream/hubert/hubconf.py:29-156):
+``hubert_custom(ckpt, legacy=False, fairseq=False, refresh=False, **kwargs)``, its aliases ``hubert_local`` /
+``hubert_url``, and every released model (``hubert``, ``hubert_base``, ``hubert_large_ll60k``, ``hubert_base_robust_mgr``,
+``mhubert_base_vp_en_es_fr_it3``, ``contentvec*``, ``ms_hubert``).  An ``http`` checkpoint resolves to the reference's own
+cache file (``s3prl_amd.download``: ``~/.cache/s3prl/download/<sha256(url)>.<name>``, fetched when absent and a network
+exists); ``fairseq=True`` reads the fairseq checkpoint layout directly (``s3prl_amd.ckpt``); ``legacy=True`` (the
+reference's LegacyUpstreamExpert imports the ``fairseq`` package itself) raises."""
 
 import os
 
 from ...ckpt import convert_fairseq_checkpoint as _convert_fairseq_checkpoint
+from ...download import urls_to_filepaths as _urls_to_filepaths
+from .. import _released
 from .expert import UpstreamExpert as _UpstreamExpert
+
+_CONVERTED = "https://huggingface.co/s3prl/converted_ckpts/resolve/main/"
 
 
 def hubert_custom(ckpt: str, legacy: bool = False, fairseq: bool = False, refresh: bool = False, **kwargs):
@@ -19,7 +26,7 @@ def hubert_custom(ckpt: str, legacy: bool = False, fairseq: bool = False, refres
             "hubert: legacy=True loads the checkpoint through the `fairseq` package (LegacyUpstreamExpert), which the "
             "MI355X path does not depend on — convert the checkpoint (fairseq=True) instead")
     if str(ckpt).startswith("http"):
-        raise RuntimeError(f"hubert: no network in this build, cannot fetch {ckpt} — pass a local checkpoint path")
+        ckpt = _urls_to_filepaths(str(ckpt), refresh=refresh)
     if fairseq:
         ckpt = _convert_fairseq_checkpoint(str(ckpt), "hubert", refresh=refresh)
     assert os.path.isfile(ckpt), ckpt
@@ -34,8 +41,19 @@ def hubert_url(*args, **kwargs):
     return hubert_custom(*args, **kwargs)
 
 
-def hubert(refresh=False, *args, **kwargs):
-    """The reference's default entry downloads a released checkpoint; here it needs ``ckpt=`` (a local file)."""
-    if "ckpt" not in kwargs and not args:
-        raise RuntimeError("hubert: no network in this build — pass ckpt=<converted checkpoint> (see hubert_local)")
-    return hubert_custom(*args, refresh=refresh, **kwargs)
+hubert = _released.alias("hubert", lambda: hubert_base, "The default model - Base (hubert/hubconf.py:77-82)")
+hubert_base = _released.with_legacy(
+    "hubert_base", hubert_custom, _CONVERTED + "hubert_base_ls960.pt",
+    "https://dl.fbaipublicfiles.com/hubert/hubert_base_ls960.pt")
+hubert_large_ll60k = _released.with_legacy(
+    "hubert_large_ll60k", hubert_custom, _CONVERTED + "hubert_large_ll60k.pt",
+    "https://dl.fbaipublicfiles.com/hubert/hubert_large_ll60k.pt")
+hubert_base_robust_mgr = _released.with_legacy(
+    "hubert_base_robust_mgr", hubert_custom, _CONVERTED + "HuBERT_base_robust_mgr_best_loss_2.7821.pt",
+    "https://huggingface.co/kphuang68/HuBERT_base_robust_mgr/resolve/main/HuBERT_base_robust_mgr_best_loss_2.7821.pt")
+mhubert_base_vp_en_es_fr_it3 = _released.converted_only(
+    "mhubert_base_vp_en_es_fr_it3", hubert_custom, _CONVERTED + "mhubert_base_vp_en_es_fr_it3.pt")
+contentvec = _released.converted_only("contentvec", hubert_custom, _CONVERTED + "contentvec_km100.pt")
+contentvec_km100 = _released.converted_only("contentvec_km100", hubert_custom, _CONVERTED + "contentvec_km100.pt")
+contentvec_km500 = _released.converted_only("contentvec_km500", hubert_custom, _CONVERTED + "contentvec_km500.pt")
+ms_hubert = _released.converted_only("ms_hubert", hubert_custom, "https://huggingface.co/s3prl/MS-HuBERT/resolve/main/iter3.pt")

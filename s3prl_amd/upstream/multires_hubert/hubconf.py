@@ -1,15 +1,19 @@
-"""hub entries in the reference's naming convention (s3prl/upstream/multires_hubert/hubconf.py:22-95):
-``multires_hubert_custom(ckpt, refresh=False, **kwargs)`` / ``multires_hubert_local``; the released-checkpoint names need
-``ckpt=`` here (no network)."""
+"""hub entries of multires-HuBERT under the reference's names and signatures
+(s3prl/upstream/multires_hubert/hubconf.py:29-95): ``multires_hubert_custom(ckpt, refresh=False, **kwargs)`` /
+``multires_hubert_local`` and the five released names.  URLs resolve to the reference's cache file (``s3prl_amd.download``)."""
 
 import os
 
+from ...download import urls_to_filepaths as _urls_to_filepaths
+from .. import _released
 from .expert import UpstreamExpert as _UpstreamExpert
+
+_MR = "https://huggingface.co/s3prl/mr_hubert/resolve/main/"
 
 
 def multires_hubert_custom(ckpt: str, refresh: bool = False, **kwargs):
     if str(ckpt).startswith("http"):
-        raise RuntimeError(f"multires_hubert: no network in this build, cannot fetch {ckpt} — pass a local checkpoint path")
+        ckpt = _urls_to_filepaths(str(ckpt), refresh=refresh)
     assert os.path.isfile(ckpt), ckpt
     return _UpstreamExpert(str(ckpt), **kwargs)
 
@@ -18,18 +22,11 @@ def multires_hubert_local(*args, **kwargs):
     return multires_hubert_custom(*args, **kwargs)
 
 
-def _released(name):
-    def entry(refresh=False, *args, **kwargs):
-        if "ckpt" not in kwargs and not args:
-            raise RuntimeError(f"{name}: no network in this build — pass ckpt=<converted checkpoint> (see multires_hubert_local)")
-        return multires_hubert_custom(*args, refresh=refresh, **kwargs)
-
-    entry.__name__ = name
-    return entry
-
-
-multires_hubert_base = _released("multires_hubert_base")
-multires_hubert_large = _released("multires_hubert_large")
-multires_hubert_multilingual_base = _released("multires_hubert_multilingual_base")
-multires_hubert_multilingual_large400k = _released("multires_hubert_multilingual_large400k")
-multires_hubert_multilingual_large600k = _released("multires_hubert_multilingual_large600k")
+multires_hubert_base = _released.converted_only("multires_hubert_base", multires_hubert_custom, _MR + "mrhubert_mono_base.pt", kw="kwargs")
+multires_hubert_large = _released.converted_only("multires_hubert_large", multires_hubert_custom, _MR + "mrhubert_mono_large.pt", kw="kwargs")
+multires_hubert_multilingual_base = _released.converted_only(
+    "multires_hubert_multilingual_base", multires_hubert_custom, _MR + "multi_base.pt", kw="kwargs")
+multires_hubert_multilingual_large400k = _released.converted_only(
+    "multires_hubert_multilingual_large400k", multires_hubert_custom, _MR + "multi_large_400k.pt", kw="kwargs")
+multires_hubert_multilingual_large600k = _released.converted_only(
+    "multires_hubert_multilingual_large600k", multires_hubert_custom, _MR + "multi_large_600k.pt", kw="kwargs")

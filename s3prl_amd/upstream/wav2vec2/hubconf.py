@@ -1,16 +1,24 @@
-"""hub entries in the reference's naming convention (s3prl/upstream/wav2vec2/hubconf.py:28-81): ``wav2vec2_custom(ckpt,
-legacy=False, fairseq=False, refresh=False, **kwargs)`` and its aliases ``wav2vec2_local`` / ``wav2vec2_url``.  This build has
-no network: ``http`` sources raise; ``fairseq=True`` reads the fairseq checkpoint layout directly (``s3prl_amd.ckpt``);
-``legacy=True`` (the reference's LegacyUpstreamExpert imports the ``fairseq`` package itself) raises."""
+"""hub entries of the wav2vec 2.0 family under the reference's names and signatures
+(s3prl/upstream/wav2vec2/hubconf.py:28-270): ``wav2vec2_custom(ckpt, legacy=False, fairseq=False, refresh=False,
+**kwargs)``, ``wav2vec2_local`` / ``wav2vec2_url``, and every released model (``wav2vec2``, ``wav2vec2_base_960``,
+``wav2vec2_large_960``, ``wav2vec2_large_ll60k``, ``wav2vec2_large_lv60_cv_swbd_fsh``, ``xlsr_53``, ``xls_r_300m/1b/2b``,
+the VoxPopuli / S2ST transformer models).  ``http`` checkpoints resolve to the reference's cache file
+(``s3prl_amd.download``).  The conformer-typed names (``layer_type="conformer"``, wav2vec2_model.py:2100,2958) are
+registered and raise ``NotImplementedError``: the MI355X path builds the Transformer block only."""
 
 import os
 
 from ...ckpt import convert_fairseq_checkpoint as _convert_fairseq_checkpoint
+from ...download import urls_to_filepaths as _urls_to_filepaths
+from .. import _released
 from .expert import UpstreamExpert as _UpstreamExpert
+
+_CONVERTED = "https://huggingface.co/s3prl/converted_ckpts/resolve/main/"
+_FAIRSEQ = "https://dl.fbaipublicfiles.com/fairseq/"
 
 
 def wav2vec2_custom(ckpt: str, legacy: bool = False, fairseq: bool = False, refresh: bool = False, **kwargs):
-    # AssertionError like the reference entry (hubert/hubconf.py:36-41): the two loaders are mutually exclusive
+    # AssertionError like the reference entry (wav2vec2/hubconf.py:35-40): the two loaders are mutually exclusive
     assert not (legacy and fairseq), (
         f"{__name__}: pass either legacy=True (load through the fairseq package) or fairseq=True (convert the fairseq "
         "checkpoint first), not both")
@@ -19,7 +27,7 @@ def wav2vec2_custom(ckpt: str, legacy: bool = False, fairseq: bool = False, refr
             "wav2vec2: legacy=True loads the checkpoint through the `fairseq` package (LegacyUpstreamExpert), which the "
             "MI355X path does not depend on — convert the checkpoint (fairseq=True) instead")
     if str(ckpt).startswith("http"):
-        raise RuntimeError(f"wav2vec2: no network in this build, cannot fetch {ckpt} — pass a local checkpoint path")
+        ckpt = _urls_to_filepaths(str(ckpt), refresh=refresh)
     if fairseq:
         ckpt = _convert_fairseq_checkpoint(str(ckpt), "wav2vec2", refresh=refresh)
     assert os.path.isfile(ckpt), ckpt
@@ -34,8 +42,28 @@ def wav2vec2_url(*args, **kwargs):
     return wav2vec2_custom(*args, **kwargs)
 
 
-def wav2vec2(refresh=False, *args, **kwargs):
-    """The reference's default entry downloads a released checkpoint; here it needs ``ckpt=`` (a local file)."""
-    if "ckpt" not in kwargs and not args:
-        raise RuntimeError("wav2vec2: no network in this build — pass ckpt=<converted checkpoint> (see wav2vec2_local)")
-    return wav2vec2_custom(*args, refresh=refresh, **kwargs)
+wav2vec2 = _released.alias("wav2vec2", lambda: wav2vec2_base_960, "The default model - Base (wav2vec2/hubconf.py:76-81)")
+
+# name -> (converted file under s3prl/converted_ckpts, original fairseq URL used with legacy=True)
+_TRANSFORMER_MODELS = {
+    "wav2vec2_base_960": ("wav2vec_small.pt", _FAIRSEQ + "wav2vec/wav2vec_small.pt"),
+    "wav2vec2_large_960": ("libri960_big.pt", _FAIRSEQ + "wav2vec/libri960_big.pt"),
+    "wav2vec2_large_ll60k": ("wav2vec_vox_new.pt", _FAIRSEQ + "wav2vec/wav2vec_vox_new.pt"),
+    "wav2vec2_large_lv60_cv_swbd_fsh": ("w2v_large_lv_fsh_swbd_cv.pt", _FAIRSEQ + "wav2vec/w2v_large_lv_fsh_swbd_cv.pt"),
+    "xlsr_53": ("xlsr_53_56k.pt", _FAIRSEQ + "wav2vec/xlsr_53_56k.pt"),
+    "xls_r_300m": ("xlsr2_300m.pt", _FAIRSEQ + "wav2vec/xlsr2_300m.pt"),
+    "xls_r_1b": ("xlsr2_960m_1000k.pt", _FAIRSEQ + "wav2vec/xlsr2_960m_1000k.pt"),
+    "xls_r_2b": ("xlsr2_2B_1000k.pt", _FAIRSEQ + "wav2vec/xlsr2_2B_1000k.pt"),
+    "wav2vec2_large_voxpopuli_100k": ("wav2vec2_large_100k.pt", "https://dl.fbaipublicfiles.com/voxpopuli/models/wav2vec2_large_100k.pt"),
+    "wav2vec2_base_s2st_es_voxpopuli": ("wav2vec2_base_s2st_es_voxpopuli.pt", _FAIRSEQ + "speech_to_speech/s2st_finetuning/w2v2/es/transformer_B.pt"),
+    "wav2vec2_base_s2st_en_librilight": ("wav2vec2_base_s2st_en_librilight.pt", _FAIRSEQ + "speech_to_speech/s2st_finetuning/w2v2/en/transformer_B.pt"),
+}
+for _name, (_file, _legacy_url) in _TRANSFORMER_MODELS.items():
+    globals()[_name] = _released.with_legacy(_name, wav2vec2_custom, _CONVERTED + _file, _legacy_url)
+
+_CONFORMER = ("conformer encoder layers (layer_type='conformer': depthwise-conv module + relative / rotary attention, "
+              "wav2vec2_model.py:2100,2958) are outside the MI355X hot path, which builds the Transformer block")
+for _name in ("wav2vec2_conformer_relpos", "wav2vec2_conformer_rope", "wav2vec2_conformer_large_s2st_es_voxpopuli",
+              "wav2vec2_conformer_large_s2st_en_librilight"):
+    globals()[_name] = _released.unsupported(_name, _CONFORMER)
+del _name, _file, _legacy_url

@@ -93,3 +93,65 @@ def test_multires_geometry_and_config_parsing():
         config_from_multires(dict(label_rate_ratios="None"))
     with pytest.raises(ValueError, match="divide"):
         config_from_multires(dict(label_rate_ratios=[1, 5]))
+
+
+def test_released_name_is_served_from_the_reference_cache_file(tmp_path, monkeypatch):
+    """``hubert_base()`` (hubert/hubconf.py:85-95) resolves its URL to ``<dir>/<sha256(url)>.<basename>`` — the file the
+    reference's downloader writes (util/download.py:186-208) — and loads it when present; absent and without network the
+    error names that path."""
+    import hashlib
+
+    import s3prl_amd.hub as amd
+    from s3prl_amd import download
+    from s3prl_amd.ckpt import save_checkpoint
+    from s3prl_amd.synth import named_config, synth_weights
+
+    monkeypatch.setattr(download, "TIMEOUT_SECS", 2.0)
+    old = download.get_dir()
+    download.set_dir(tmp_path / "cache")
+    try:
+        url = amd.hubert_base.url
+        assert url.startswith("https://huggingface.co/s3prl/converted_ckpts/") and url.endswith("hubert_base_ls960.pt")
+        expected = tmp_path / "cache" / f"{hashlib.sha256(url.encode()).hexdigest()}.hubert_base_ls960.pt"
+        assert download.cache_path(url) == expected
+        with pytest.raises(RuntimeError, match="hubert_base_ls960.pt"):   # no network here: nothing to load yet
+            amd.hubert_base()
+        cfg = named_config("tiny_hubert")
+        save_checkpoint(str(expected), cfg, synth_weights(cfg, 0))
+        expert = amd.hubert_base(refresh=False)
+        assert expert.cfg.to_dict() == cfg.to_dict()
+        assert amd.hubert().cfg.to_dict() == cfg.to_dict()                 # the family default = Base (hubconf.py:77-82)
+        with pytest.raises(NotImplementedError, match="fairseq"):
+            amd.hubert_base(legacy=True)
+        with pytest.raises(NotImplementedError, match="conformer"):
+            amd.wav2vec2_conformer_relpos()
+        wcfg = named_config("tiny_wavlm")
+        wurl = amd.wavlm_base_plus.url
+        save_checkpoint(str(download.cache_path(wurl)), wcfg, synth_weights(wcfg, 0))
+        assert amd.wavlm().cfg.to_dict() == wcfg.to_dict()                 # WavLM's default = Base+ (wavlm/hubconf.py:37-42)
+    finally:
+        download.set_dir(old)
+
+
+def test_fine_tuning_flow_raises_at_backward_instead_of_silently_freezing():
+    """The reference's `upstream_trainable` flow (downstream/runner.py:258-262,296-301): `.train()` + a forward with autograd
+    on.  The expert has no parameters, so the states of such a forward carry a node whose backward raises; frozen use
+    (`.eval()` or `no_grad`) returns plain constants."""
+    import torch
+
+    from s3prl_amd.upstream.base import HipUpstreamExpert
+    from s3prl_amd.synth import named_config, synth_weights
+
+    cfg = named_config("tiny_hubert")
+    expert = HipUpstreamExpert.from_weights(cfg, synth_weights(cfg, 0))
+    assert list(expert.parameters()) == []
+    slab = torch.zeros(4, 2, 5, 8)
+    expert.train()
+    guarded = expert._guard_backward(slab)
+    assert guarded.requires_grad and torch.equal(guarded, slab)
+    with pytest.raises(RuntimeError, match="inference-only"):
+        (guarded.sum() * 2).backward()
+    with torch.no_grad():
+        assert not expert._guard_backward(slab).requires_grad
+    expert.eval()
+    assert expert._guard_backward(slab) is slab

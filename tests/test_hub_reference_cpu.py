@@ -52,6 +52,50 @@ def test_register_into_the_real_hub_and_signatures(tmp_path):
     assert out.returncode == 0 and "REFERENCE_HUB_OK" in out.stdout, out.stderr[-3000:]
 
 
+_NAMES_SCRIPT = r"""
+import importlib, inspect, os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests", "golden"))
+import ref_shim
+ref_shim.import_reference()
+import s3prl.hub as ref_hub          # the REAL reference hub
+import s3prl_amd.hub as amd
+checked = 0
+for family in ("hubert", "wav2vec2", "wavlm", "unispeech_sat", "data2vec", "distiller", "multires_hubert", "hf_hubert", "hf_wav2vec2"):
+    ref_conf = importlib.import_module(f"s3prl.upstream.{family}.hubconf")
+    for name, fn in vars(ref_conf).items():
+        if name.startswith("_") or not inspect.isfunction(fn) or fn.__module__ != ref_conf.__name__:
+            continue
+        assert getattr(ref_hub, name) is fn, name                   # it IS a name the reference hub serves
+        assert hasattr(amd, name), f"{family}: s3prl_amd.hub lacks {name}"
+        ref, ours = inspect.signature(fn), inspect.signature(getattr(amd, name))
+        assert [(k, v.kind, v.default) for k, v in ref.parameters.items()] == \
+               [(k, v.kind, v.default) for k, v in ours.parameters.items()], (name, str(ref), str(ours))
+        assert name in amd.options(), name
+        checked += 1
+assert checked >= 60, checked
+# the released names are not "_local / _url / _custom" entries: S3PRLUpstream.available_names(only_registered_ckpt=True)
+reg = set(amd.options(only_registered_ckpt=True))
+assert {"hubert_base", "hubert_large_ll60k", "wav2vec2_large_ll60k", "xls_r_300m", "wavlm_large", "wavlm_base_plus",
+        "unispeech_sat_large", "data2vec_large_ll60k", "contentvec"} <= reg
+# cache naming rule = the reference's (util/download.py:186-208)
+from s3prl.util import download as ref_dl
+from s3prl_amd import download as our_dl
+ref_dl.set_dir(sys.argv[2]); our_dl.set_dir(sys.argv[2])
+for url in (amd.hubert_base.url, amd.wavlm_large.url, amd.xlsr_53.legacy_url):
+    assert ref_dl._urls_to_filepaths(url, download=False) == our_dl.urls_to_filepaths(url, download=False), url
+print("REFERENCE_NAMES_OK", checked)
+"""
+
+
+def test_every_released_name_of_the_reference_hubconfs_exists_with_the_same_signature(tmp_path):
+    """`-u hubert_large_ll60k`, `S3PRLUpstream("wavlm_large")`: how every SUPERB recipe names an upstream."""
+    import subprocess
+
+    root = os.path.dirname(HERE)
+    out = subprocess.run([sys.executable, "-c", _NAMES_SCRIPT, root, str(tmp_path)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "REFERENCE_NAMES_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
 def test_custom_entry_rejects_legacy_plus_fairseq():
     import s3prl_amd.hub as amd
 
