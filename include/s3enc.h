@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define S3ENC_VERSION 5
+#define S3ENC_VERSION 6
 #define S3ENC_MAX_CONV 16
 #define S3ENC_MAX_RES 4 /* resolutions of a multires-HuBERT U-net: up to 3 rate pairs, 7 encoder blocks */
 
@@ -166,6 +166,19 @@ int s3enc_num_states(s3enc_handle h, int32_t selection, int32_t* n);
  * out + i*layer_stride ELEMENTS of out_dtype (featurize: one fp32 (B, T, D) block, layer_stride ignored). */
 int s3enc_forward_ex(s3enc_handle h, const float* const* wavs, const int64_t* lengths, int32_t B, int64_t n_max,
                      const s3enc_forward_opts* opts, void* out, int64_t layer_stride, void* stream);
+
+/* Numerical health of the forwards of this handle (ABI 6).  Replaces: nothing the reference has as a call — its
+ * experts return whatever ATen computed and the regression test inspects the tensors (test/test_upstream.py:118-136);
+ * a 16-bit compute mode can overflow where fp32 cannot (fp16: |x| > 65504), so the library reports it instead of leaving
+ * the caller to scan (NS, B, T, D) states.  `*status` = OR of S3ENC_STATUS_* over every FINISHED forward since the last
+ * call; reading clears.  S3ENC_STATUS_NONFINITE: some row LayerNorm met a non-finite mean / variance — every hidden state
+ * is a LayerNorm output (post-LN models) or the next LayerNorm's input (pre-LN residual streams), so an inf / NaN that
+ * reaches the states is seen; the states of that forward must not be trusted.  wait != 0: block until every forward
+ * enqueued so far has finished on its stream; wait == 0: never blocks — forwards still running are reported by the bit
+ * S3ENC_STATUS_PENDING and their own bits by a later call (host-side cost of a poll: a few hipEventQuery; each forward
+ * copies its word to a pinned ring of 8 slots, so nothing here touches the device). */
+enum { S3ENC_STATUS_NONFINITE = 1, S3ENC_STATUS_PENDING = 1 << 30 };
+int s3enc_forward_status(s3enc_handle h, int32_t wait, int32_t* status);
 
 /* Optional: `n` = encoder_layers+1 hipEvent_t handles (as void*); the following forwards record events[l] on the
  * launch stream as soon as hidden_states[l] is final, so a communication stream can start the all-gather of layer l

@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libs3enc.so")
 S3ENC_MAX_CONV = 16
 S3ENC_MAX_RES = 4
 F32, BF16, F16, F32X3, F16X2 = 0, 1, 2, 3, 4
+STATUS_NONFINITE, STATUS_PENDING = 1, 1 << 30  # s3enc_forward_status bits (include/s3enc.h)
 DTYPES = {"fp32": F32, "f32": F32, "float32": F32, "bf16": BF16, "bfloat16": BF16, "fp16": F16, "f16": F16,
           "float16": F16, "fp32x3": F32X3, "f32x3": F32X3, "bf16x3": F32X3,
           "fp16x2": F16X2, "f16x2": F16X2}
@@ -22,7 +23,7 @@ FAMILY = {"hubert": 0, "wav2vec2": 1, "wavlm": 2, "distiller": 3, "multires_hube
 SEL_HIDDEN, SEL_LAYER_OUT, SEL_FFN_OUT = 0, 1, 2
 SELECTIONS = {None: SEL_HIDDEN, "hidden_states": SEL_HIDDEN, "fairseq_layers": SEL_LAYER_OUT,
               "fairseq_layers_before_residual": SEL_FFN_OUT}
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class S3Config(C.Structure):
@@ -71,6 +72,7 @@ _PROTOS = {
     "s3enc_downsample_rate": (C.c_int, [_VP, C.POINTER(_I32)]),
     "s3enc_valid_frames": (C.c_int, [_VP, _I64, _I64, C.POINTER(_I32)]),
     "s3enc_forward": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(_I64), _I32, _I64, _VP, _I64, _VP]),
+    "s3enc_forward_status": (C.c_int, [_VP, _I32, C.POINTER(_I32)]),
     "s3enc_forward_ex": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(_I64), _I32, _I64, C.POINTER(S3ForwardOpts), _VP, _I64, _VP]),
     "s3enc_num_states": (C.c_int, [_VP, _I32, C.POINTER(_I32)]),
     "s3enc_forward_padded": (C.c_int, [_VP, _VP, _I64, C.POINTER(_I64), _I32, _I64, _VP, _I64, _VP]),

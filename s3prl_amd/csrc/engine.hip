@@ -471,6 +471,15 @@ int s3enc_create(const s3enc_config* cfg, const s3enc_tensor* tensors, int32_t n
             return fail("hipEventCreate failed");
         }
     }
+    // the status word of s3enc_forward_status: device int + pinned host copy + the event behind the copy
+    bool st_ok = e->status_dev.ensure(64) == hipSuccess && hipMemset(e->status_dev.p, 0, 64) == hipSuccess &&
+                 hipHostMalloc((void**)&e->status_host, s3enc_encoder::STATUS_RING * sizeof(int), hipHostMallocDefault) == hipSuccess;
+    for (int i = 0; st_ok && i < s3enc_encoder::STATUS_RING; ++i)
+        st_ok = hipEventCreateWithFlags(&e->status_ev[i], hipEventDisableTiming) == hipSuccess;
+    if (!st_ok) {
+        delete e;
+        return fail("s3enc_create: status word allocation failed");
+    }
     *out = e;
     return 0;
 }
@@ -553,10 +562,35 @@ struct Sink {
     }
 };
 
+int forward_body(s3enc_handle e, const float* const* wav_ptrs_host, const int64_t* lengths, int32_t B, int64_t n_max_in,
+                 const FwdOpts& fo, void* out, int64_t layer_stride, hipStream_t st);
+
+// The forward proper runs with the handle's tuning and status word current for this thread.  The word is cleared in front of
+// it and copied to the next pinned slot behind it, with an event, so that s3enc_forward_status never has to touch the device.
 int forward_impl(s3enc_handle e, const float* const* wav_ptrs_host, const int64_t* lengths, int32_t B, int64_t n_max_in,
                  const FwdOpts& fo, void* out, int64_t layer_stride, hipStream_t st) {
-    const s3enc_config& c = e->cfg;
     TuningScope tuning_scope(e->has_tuning ? &e->tun : nullptr);
+    StatusScope status_scope((int*)e->status_dev.p);
+    HIP_TRY(hipMemsetAsync(e->status_dev.p, 0, sizeof(int), st));
+    const int rc = forward_body(e, wav_ptrs_host, lengths, B, n_max_in, fo, out, layer_stride, st);
+    if (rc == 0) {
+        const int slot = e->status_next;
+        if (e->status_busy[slot]) {  // STATUS_RING forwards ago: finished long since unless the host ran far ahead
+            HIP_TRY(hipEventSynchronize(e->status_ev[slot]));
+            e->status_sticky |= ((volatile int*)e->status_host)[slot];
+            e->status_busy[slot] = false;
+        }
+        HIP_TRY(hipMemcpyAsync(e->status_host + slot, e->status_dev.p, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipEventRecord(e->status_ev[slot], st));
+        e->status_busy[slot] = true;
+        e->status_next = (slot + 1) % s3enc_encoder::STATUS_RING;
+    }
+    return rc;
+}
+
+int forward_body(s3enc_handle e, const float* const* wav_ptrs_host, const int64_t* lengths, int32_t B, int64_t n_max_in,
+                 const FwdOpts& fo, void* out, int64_t layer_stride, hipStream_t st) {
+    const s3enc_config& c = e->cfg;
     const int C = c.conv_dim, D = c.embed_dim, F = c.ffn_dim, H = c.heads, NL = c.encoder_layers;
     const int dt = e->dtype, es = e->es;
     const bool dist = c.family == S3ENC_DISTILLER;
@@ -1178,6 +1212,15 @@ int s3enc_forward_ex(s3enc_handle h, const float* const* wavs, const int64_t* le
     FwdOpts fo;
     if (parse_opts(h, opts, fo)) return 1;
     return forward_impl(h, wavs, lengths, B, n_max, fo, out, layer_stride, (hipStream_t)stream);
+}
+
+int s3enc_forward_status(s3enc_handle h, int32_t wait, int32_t* status) {
+    if (!h || !status) return fail("s3enc_forward_status: null argument");
+    DeviceGuard dg(h->device);
+    const int running = h->status_collect(wait != 0);
+    *status = h->status_sticky | (running ? S3ENC_STATUS_PENDING : 0);
+    h->status_sticky = 0;
+    return 0;
 }
 
 int s3enc_num_states(s3enc_handle h, int32_t selection, int32_t* n) {

@@ -299,6 +299,35 @@ struct s3enc_encoder {
 
     std::vector<hipEvent_t> layer_events;  // caller-owned, recorded when hidden_states[l] is final
 
+    // s3enc_forward_status (ABI 6): the device word the row kernels OR into (kernels.h, t_status) is cleared at the start of
+    // every forward and copied at its end into the next slot of a small pinned ring, with an event behind the copy — so a
+    // status read folds the slots whose event has fired and never touches the device; a host running more than STATUS_RING
+    // forwards ahead of the GPU waits for the oldest one when it comes round to its slot
+    static constexpr int STATUS_RING = 8;
+    DevBuf status_dev;
+    int* status_host = nullptr;  // STATUS_RING words
+    hipEvent_t status_ev[STATUS_RING] = {};
+    bool status_busy[STATUS_RING] = {};
+    int status_next = 0;
+    int status_sticky = 0;  // bits of finished forwards not yet handed to the caller
+    // fold the finished slots into status_sticky; wait: block for all of them.  Returns the number still running.
+    int status_collect(bool wait) {
+        int running = 0;
+        for (int k = 0; k < STATUS_RING; ++k) {
+            const int i = (status_next + k) % STATUS_RING;  // oldest first
+            if (!status_busy[i]) continue;
+            const hipError_t q = wait ? hipEventSynchronize(status_ev[i]) : hipEventQuery(status_ev[i]);
+            if (q == hipErrorNotReady) {
+                (void)hipGetLastError();
+                ++running;
+                continue;
+            }
+            status_busy[i] = false;
+            if (q == hipSuccess) status_sticky |= ((volatile int*)status_host)[i];
+        }
+        return running;
+    }
+
     // profiling
     int prof = 0;  // 0 off, 1 every kernel, 2 only the GEMM launches (the dominant kernel: cheap enough for a timed region)
     std::vector<std::string> kinds;
@@ -324,6 +353,9 @@ struct s3enc_encoder {
         for (int i = 0; i < RING; ++i)
             if (slot_ev[i]) (void)hipEventDestroy(slot_ev[i]);
         if (pinned) (void)hipHostFree(pinned);
+        if (status_host) (void)hipHostFree(status_host);
+        for (int i = 0; i < STATUS_RING; ++i)
+            if (status_ev[i]) (void)hipEventDestroy(status_ev[i]);
     }
 
     int kind_id(const char* name) {

@@ -51,6 +51,18 @@ struct TuningScope {
 };
 int tuning_set(Tuning& t, const char* key, int value, const char** err);  // 0 ok; ops.hip
 
+// ---- forward status word (s3enc_forward_status, ABI 6) ---------------------------------------------------------
+// A device int32 owned by the handle; the row LayerNorm kernels OR bit 0 into it when a row's mean or variance is not
+// finite (every hidden state passes through one of them: a post-LN state IS a LayerNorm output, a pre-LN residual stream
+// is the next LayerNorm's input) — the symptom of a 16-bit overflow upstream of the row, or of non-finite PCM.  Current for
+// the calling thread while a handle's forward enqueues its kernels, like the tuning scope above; null outside.
+extern thread_local int* t_status;
+struct StatusScope {
+    int* prev;
+    explicit StatusScope(int* p) : prev(t_status) { t_status = p; }
+    ~StatusScope() { t_status = prev; }
+};
+
 // ---- gemm.hip -----------------------------------------------------------------------------------------
 struct GemmParams {
     const void* A;  // (batches, M, K) rows at A + b*a_bs + m*lda (elements of the compute dtype)

@@ -15,7 +15,7 @@ namespace {
 template <typename T, int NCH>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, long rows, int C, int act,
-                                                        float* out32, void* out16, LnAcc fa, LnGate gt) {
+                                                        float* out32, void* out16, LnAcc fa, LnGate gt, int* status) {
     typedef typename Cvt<T>::store_t store_t;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -41,7 +41,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
             q += (a * a + b * b) + (c * c + d * d);
         }
     }
-    const float rs = rsqrtf(wave_sum(q) * invC + LN_EPS);
+    const float var = wave_sum(q) * invC;
+    const float rs = rsqrtf(var + LN_EPS);
+    // a non-finite element makes mu or var non-finite (inf - inf = NaN): one atomic on the rare path, nothing on the common one
+    if (status && lane == 0 && !(fabsf(mu) <= 3.0e38f && var <= 3.0e38f)) atomicOr(status, 1);
     if (fa.mode == 1) {  // the INPUT row is a state: acc (+)= w * x, or w * (x - mu) * rs with the statistics above
         const float a = fa.norm ? fa.w * rs : fa.w, c0 = fa.norm ? -mu * a : 0.f;
 #pragma unroll
@@ -231,7 +234,7 @@ hipError_t ln_dispatch(const float* x, const float* gamma, const float* beta, lo
                        void* out16, const LnAcc& fa, const LnGate& gt, hipStream_t s) {
     const int per_lane = ((C >> 2) + 63) / 64;
     dim3 grid((unsigned)((rows + 3) / 4)), block(256);
-#define S3_LN(N) hipLaunchKernelGGL((layernorm_kernel<T, N>), grid, block, 0, s, x, gamma, beta, rows, C, act, out32, out16, fa, gt)
+#define S3_LN(N) hipLaunchKernelGGL((layernorm_kernel<T, N>), grid, block, 0, s, x, gamma, beta, rows, C, act, out32, out16, fa, gt, t_status)
     if (per_lane <= 1) S3_LN(1);
     else if (per_lane == 2) S3_LN(2);
     else if (per_lane == 3) S3_LN(3);

@@ -5,6 +5,7 @@
 namespace s3 {
 Tuning g_tuning;
 thread_local const Tuning* t_tuning = nullptr;
+thread_local int* t_status = nullptr;
 
 int tuning_set(Tuning& t, const char* key, int value, const char** err) {
     struct Key {

@@ -16,12 +16,20 @@ class HipEncoder:
     """wav2vec2 / HuBERT / WavLM encoder forward on one MI355X through ``libs3enc.so``."""
 
     def __init__(self, cfg: EncoderConfig, weights: Dict[str, "np.ndarray"], dtype: str = "fp32",
-                 device: Optional[int] = None):
+                 device: Optional[int] = None, check: Optional[str] = None):
+        """``check``: what a forward does about the library's non-finite flag (``check_finite``) — "deferred" (default: a
+        non-blocking poll after every forward, so an overflow raises at the latest on the next forward), "strict" (one
+        stream synchronisation per forward, raises on the forward that overflowed) or "off"; env ``S3PRL_AMD_CHECK``."""
+        import os
+
         import torch
 
         cfg.validate()
         self.cfg = cfg
         self.dtype = dtype
+        self.check = check or os.environ.get("S3PRL_AMD_CHECK", "deferred")
+        if self.check not in ("deferred", "strict", "off"):
+            raise ValueError(f"check must be 'deferred', 'strict' or 'off', not {self.check!r}")
         self._lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.S3EncError("no GPU visible: the s3prl_amd encoder has no CPU fallback (use the reference s3prl on CPU)")
@@ -87,6 +95,34 @@ class HipEncoder:
         _lib.check(self._lib.s3enc_num_states(self._h, _lib.SELECTIONS[selection], C.byref(n)), "s3enc_num_states")
         return n.value
 
+    # ---- numerical health (s3enc_forward_status, ABI 6) ----
+    def status(self, wait: bool = True) -> int:
+        """OR of the status bits of every FINISHED forward since the last read (0 = healthy; reading clears).  ``wait=False``
+        never blocks: ``_lib.STATUS_PENDING`` is set while forwards are still running (their bits come with a later read)."""
+        st = C.c_int32()
+        _lib.check(self._lib.s3enc_forward_status(self._h, int(bool(wait)), C.byref(st)), "s3enc_forward_status")
+        return st.value
+
+    def check_finite(self, wait: bool = True) -> None:
+        """Raise ``FloatingPointError`` if a forward since the last check produced a non-finite LayerNorm statistic — in the
+        16-bit modes the sign of an fp16 / bf16 overflow on the way to the hidden states (an fp32 run only gets there from
+        non-finite PCM).  ``wait=False`` never blocks: a forward still in flight is checked by the next call."""
+        st = self.status(wait)
+        if st & _lib.STATUS_NONFINITE:
+            raise FloatingPointError(
+                f"libs3enc ({self.dtype}): a forward produced non-finite activations (a row LayerNorm met an inf / NaN "
+                "mean or variance) — its hidden states are not valid.  In fp16 / fp16x2 this is a range overflow "
+                "(|x| > 65504): use compute dtype fp32x3 / fp32 (or bf16) for this checkpoint; in fp32 check the waveforms")
+
+    def _after_forward(self):
+        # strict: the caller pays one stream synchronisation per forward and gets the error on the forward that overflowed;
+        # deferred (default): a non-blocking poll of the forwards that have finished — an overflow surfaces on one of the next
+        # forwards (as soon as the host is no longer ahead of it) or at check_finite()
+        if self.check == "strict":
+            self.check_finite(wait=True)
+        elif self.check == "deferred":
+            self.check_finite(wait=False)
+
     # ---- forward ----
     def _prepare(self, wavs, n_max):
         import torch
@@ -141,6 +177,7 @@ class HipEncoder:
             rc = self._lib.s3enc_forward_ex(self._h, ptrs, lens, B, nm, C.byref(opts), C.c_void_p(out.data_ptr()), B * T * D,
                                             C.c_void_p(stream))
         _lib.check(rc, "s3enc_forward")
+        self._after_forward()
         return out
 
     def forward_featurized(self, wavs: Sequence["torch.Tensor"], weights: Sequence[float], normalize: bool = False,
@@ -171,6 +208,7 @@ class HipEncoder:
             rc = self._lib.s3enc_forward_ex(self._h, ptrs, lens, B, nm, C.byref(opts), C.c_void_p(out.data_ptr()), 0,
                                             C.c_void_p(stream))
         _lib.check(rc, "s3enc_forward (featurize)")
+        self._after_forward()
         return out
 
     def layer_events(self):

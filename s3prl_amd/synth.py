@@ -185,6 +185,25 @@ def _pretrained_like(cfg: EncoderConfig, w: Dict[str, np.ndarray], seed: int) ->
     return out
 
 
+def outlier_channels(cfg: EncoderConfig, seed: int) -> np.ndarray:
+    """The residual-stream outlier channels ``_pretrained_like`` picks for (cfg, seed) (its first draw)."""
+    return np.random.default_rng([seed, 0x5EED]).choice(cfg.encoder_embed_dim, size=4, replace=False)
+
+
+def scale_outlier_writers(cfg: EncoderConfig, weights: Dict[str, np.ndarray], seed: int, factor: float) -> Dict[str, np.ndarray]:
+    """A copy of pretrained-like ``weights`` whose residual-stream writers (rows of fc2 / out_proj and their biases on the
+    outlier channels) are ``factor`` times louder: the knob of tools/fp16_cliff.py, which looks for the activation scale at
+    which each 16-bit mode leaves its tolerance or its number range."""
+    hot = outlier_channels(cfg, seed)
+    out = dict(weights)
+    for name, v in weights.items():
+        if name.endswith((".fc2.weight", ".out_proj.weight", ".fc2.bias", ".out_proj.bias")):
+            v = np.array(v, dtype=np.float32, copy=True)
+            v[hot] *= np.float32(factor)
+            out[name] = v
+    return out
+
+
 def _synthetic(cfg: EncoderConfig, seed: int = 0) -> Dict[str, np.ndarray]:
     rng = np.random.default_rng(seed)
     out: Dict[str, np.ndarray] = {}

@@ -90,6 +90,10 @@ CASES = {
     "wavlm_large_pl": ("wavlm_large", 0, 56, [16000, 12000], (4, 16), 0.0, 1.0, {"profile": "pretrained_like"}),
     "hubert_base_10s_pl": ("hubert_base", 1, 57, [160000, 123456], (8, 16), 60.0, 3000.0, {"profile": "pretrained_like"}),
     "hubert_large_10s_pl": ("hubert_large", 1, 58, [160000, 160000], (8, 32), 0.0, 1.0, {"profile": "pretrained_like"}),
+    # round 5: BASELINE configs[4]'s shape on released-checkpoint statistics — the only `*_pl` fixture whose relative positions
+    # leave the exact bucket region (|j - i| >= 80: the log-spaced buckets, the wide relative-position table the profile
+    # plants, the T = 749 LDS window of the bias) and whose padded batch masks two thirds of the keys of one utterance
+    "wavlm_large_15s_pl": ("wavlm_large", 1, 59, [240000, 61234], (8, 32), 0.0, 1.0, {"profile": "pretrained_like"}),
 }
 
 

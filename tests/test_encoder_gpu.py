@@ -416,7 +416,7 @@ PRETRAINED_LIKE = [n for n in golden_names() if n.endswith("_pl")]
 
 
 def test_pretrained_like_fixtures_are_present():
-    assert {"hubert_base_pl", "hubert_large_pl", "wavlm_large_pl", "hubert_base_10s_pl"} <= set(PRETRAINED_LIKE)
+    assert {"hubert_base_pl", "hubert_large_pl", "wavlm_large_pl", "hubert_base_10s_pl", "wavlm_large_15s_pl"} <= set(PRETRAINED_LIKE)
 
 
 @pytest.mark.parametrize("name", PRETRAINED_LIKE)
@@ -448,4 +448,87 @@ def test_16bit_modes_on_pretrained_like_statistics(name, dtype, golden_loader):
     ts, cs = meta["t_stride"], meta["c_stride"]
     errs = [O.rel_err(hs[l][:, ::ts, ::cs], golden[l]) for l in range(len(golden))]
     assert max(errs) < PL_16BIT_TOL[dtype], f"{name}/{dtype}: per-layer rel-err {['%.2e' % e for e in errs]}"
+    enc.close()
+
+
+# ---- s3enc_forward_status (ABI 6): the library reports a non-finite forward instead of leaving the caller to scan ---------
+def test_forward_status_is_clean_on_healthy_forwards_and_flags_non_finite_pcm():
+    import torch
+
+    from s3prl_amd import _lib
+    from s3prl_amd.synth import named_config, synth_wavs, synth_weights
+
+    cfg = named_config("tiny_hubert")
+    weights = synth_weights(cfg, 1)
+    wavs = synth_wavs([4000, 2345, 3111], 11)
+    bad = [w.copy() for w in wavs]
+    bad[1][1000] = np.inf
+    dev_bad = [torch.from_numpy(w).cuda() for w in bad]
+    for mode in ("fp32", "fp32x3", "fp16x2", "fp16", "bf16"):
+        enc = _encoder(cfg, weights, dtype=mode)
+        assert enc.check == "deferred"
+        hs = _run(enc, wavs)
+        assert np.isfinite(hs).all() and enc.status() == 0, mode
+        enc.check = "off"
+        out = enc.forward(dev_bad)
+        assert enc.status(wait=False) in (_lib.STATUS_PENDING, _lib.STATUS_NONFINITE)  # a poll never blocks
+        assert not np.isfinite(out.cpu().numpy()).all()
+        hs2 = _run(enc, wavs)                      # a healthy forward behind the bad one: the word is per forward ...
+        with pytest.raises(FloatingPointError, match="non-finite"):
+            enc.check_finite()                     # ... and the bad one's bit is still reported (unless the poll took it)
+            raise FloatingPointError("non-finite (taken by the poll above)")
+        assert enc.status() == 0                   # reading clears
+        assert np.array_equal(hs2, hs), mode
+        # deferred: the error surfaces on a later forward, once the host is no longer ahead of the bad one
+        enc.check = "deferred"
+        with pytest.raises(FloatingPointError):
+            enc.forward(dev_bad)
+            torch.cuda.synchronize()
+            enc.forward([torch.from_numpy(w).cuda() for w in wavs])
+        enc.status()
+        enc.close()
+
+
+def test_strict_check_raises_on_the_forward_that_overflowed_fp16_only():
+    """fc1 scaled until GELU(fc1) leaves the fp16 range (65504): the fp16 data flow stores inf as fc2's operand, the residual
+    stream turns non-finite and the next LayerNorm reports it; the same weights are finite in fp32 and bf16."""
+    import torch
+
+    from s3prl_amd.encoder import HipEncoder
+    from s3prl_amd.synth import named_config, synth_wavs, synth_weights
+
+    cfg = named_config("tiny_hubert")
+    weights = dict(synth_weights(cfg, 1))
+    for k in list(weights):
+        if k.endswith(".fc1.weight"):
+            weights[k] = weights[k] * np.float32(3e5)
+    dev = [torch.from_numpy(w).cuda() for w in synth_wavs([4000, 2345], 11)]
+    for mode, overflows in (("fp32", False), ("bf16", False), ("fp16", True), ("fp16x2", True)):
+        enc = HipEncoder(cfg, weights, dtype=mode, check="strict")
+        if overflows:
+            with pytest.raises(FloatingPointError, match="65504"):
+                enc.forward(dev)
+            assert enc.status() == 0
+        else:
+            assert torch.isfinite(enc.forward(dev)).all(), mode
+        enc.close()
+
+
+def test_status_poll_never_blocks():
+    import torch
+
+    from s3prl_amd.synth import named_config, synth_wavs, synth_weights
+
+    cfg = named_config("hubert_base")
+    enc = _encoder(cfg, synth_weights(cfg, 0))
+    enc.check = "off"
+    dev = [torch.from_numpy(w).cuda() for w in synth_wavs([48000] * 4, 3)]
+    enc.forward(dev)
+    from s3prl_amd import _lib
+
+    first = enc.status(wait=False)   # STATUS_PENDING while the forward is still running, else the (clean) mask
+    assert first in (_lib.STATUS_PENDING, 0)
+    for _ in range(20):              # more forwards in flight than the pinned ring has slots: nothing is lost or blocks for long
+        enc.forward(dev)
+    assert enc.status(wait=True) == 0
     enc.close()

@@ -14,7 +14,7 @@ from s3prl_amd.encoder import HipEncoder
 names = sys.argv[1:] or ["hubert_base_pseudo", "wav2vec2_base_pseudo", "wavlm_base_plus_pseudo", "distilhubert_pseudo",
                          "unispeech_sat_base_pseudo", "data2vec_base_pseudo", "multires_hubert_base_pseudo", "hubert_large_10s",
                          "wavlm_large_15s_pad", "hubert_base_pl", "wav2vec2_base_pl", "hubert_large_pl", "wavlm_large_pl",
-                         "hubert_base_10s_pl", "hubert_large_10s_pl"]
+                         "hubert_base_10s_pl", "hubert_large_10s_pl", "wavlm_large_15s_pl"]
 print("# Parity of the HIP encoder vs outputs of the reference itself (tests/golden, PyTorch CPU fp32), per operand mode")
 print()
 print("max / mean over the hidden states of the per-layer relative error ||h - h_ref||_F / ||h_ref||_F (SURVEY §8d); target 1e-3.")
