@@ -185,8 +185,23 @@ int s3enc_create(const s3enc_config* cfg, const s3enc_tensor* tensors, int32_t n
         }                                                            \
     } while (0)
 
+    // a GEMM weight in the handle's operand format; S3ENC_F16X2: + the MX-fp4 image of its lo term where gemm16.hip's MXW K step can
+    // take it (K % 128 == 0; wsplit_of finds the image by the weight's device pointer)
+#define UPW(buf, vec, N_, K_)                                         \
+    do {                                                              \
+        UP(upload_gemm_w(buf, vec, N_, K_, e->dtype, e->x2));         \
+        if (e->x2 && !((K_) & 127) && (N_) >= 128) {                  \
+            std::unique_ptr<MxImage> img(new MxImage());              \
+            UP(upload_mx4_lo(*img, vec, N_, K_));                     \
+            e->mx_images[(buf).p] = std::move(img);                   \
+        }                                                             \
+    } while (0)
+
     // ---- conv feature extractor ----
-    if (e->x2 && !c.extractor_layer_norm && !c.no_feature_layer_norm && c.n_conv >= 3 && C >= 128 && !(C & 31)) {
+    // (round 5: layer-norm extractors too — their conv outputs are LayerNorm'd + GELU'd, which renormalises the scale but not the
+    // relative rounding noise: six stacked fp16 roundings are 6.0e-4 on HuBERT-large and, amplified by the bias-sharpened
+    // attention of WavLM-large, 1.07e-3 alone on pretrained-like statistics — tools/fp16_error_budget.py, profiles/r05_fp16_cliff.md)
+    if (e->x2 && !c.no_feature_layer_norm && c.n_conv >= 3 && C >= 128 && !(C & 31)) {
         bool ok = true;  // every conv from the second on must be a shape the three-term GEMM takes (gemm_x3_eligible)
         for (int i = 2; i < c.n_conv; ++i) ok = ok && !(((long)c.conv_kernel[i] * C) & 31) && !(((long)c.conv_stride[i] * C * 4) & 15);
         if (ok) e->x2_conv_f32_from = 2;
@@ -204,7 +219,11 @@ int s3enc_create(const s3enc_config* cfg, const s3enc_tensor* tensors, int32_t n
             for (int co = 0; co < C; ++co)
                 for (int ci = 0; ci < cin; ++ci)
                     for (int j = 0; j < k; ++j) t2[((long)co * k + j) * cin + ci] = t[((long)co * cin + ci) * k + j];
-            UP(upload_gemm_w(e->conv[i].w, t2, C, (long)k * cin, e->dtype, e->x2));
+            if (e->x2_conv_f32_from && i >= e->x2_conv_f32_from) {
+                UP(upload_gemm_w(e->conv[i].w, t2, C, (long)k * cin, e->dtype, e->x2));  // (read only if the three-term path declines)
+            } else {
+                UPW(e->conv[i].w, t2, C, (long)k * cin);
+            }
             if (e->x3 || (e->x2_conv_f32_from && i >= e->x2_conv_f32_from)) UP(upload_x3(e->conv[i].w3, t2, C, (long)k * cin));
         }
         if (c.conv_bias) {
@@ -322,7 +341,7 @@ int s3enc_create(const s3enc_config* cfg, const s3enc_tensor* tensors, int32_t n
             for (long i = 0; i < (long)D * D; ++i) w[(long)s * D * D + i] = t[i] * sc;
             for (int i = 0; i < D; ++i) bb[(long)s * D + i] = t2[i] * sc;
         }
-        UP(upload_gemm_w(L.wqkv, w, 3L * D, D, e->dtype, e->x2));
+        UPW(L.wqkv, w, 3L * D, D);
         if (e->x3) UP(upload_x3(L.wqkv3, w, 3L * D, D));
         UP(upload_f32(L.bqkv, bb));
         GET(p + ".self_attn.out_proj.weight", (long)D * D, t);
@@ -335,12 +354,12 @@ int s3enc_create(const s3enc_config* cfg, const s3enc_tensor* tensors, int32_t n
         GET(p + ".self_attn_layer_norm.bias", D, t);
         UP(upload_f32(L.ln1b, t));
         GET(p + ".fc1.weight", (long)F * D, t);
-        UP(upload_gemm_w(L.w1, t, F, D, e->dtype, e->x2));
+        UPW(L.w1, t, F, D);
         if (e->x3) UP(upload_x3(L.w13, t, F, D));
         GET(p + ".fc1.bias", F, t);
         UP(upload_f32(L.b1, t));
         GET(p + ".fc2.weight", (long)D * F, t);
-        UP(upload_gemm_w(L.w2, t, D, F, e->dtype, e->x2));
+        UPW(L.w2, t, D, F);
         if (e->x3) UP(upload_x3(L.w23, t, D, F));
         GET(p + ".fc2.bias", D, t);
         UP(upload_f32(L.b2, t));
@@ -464,6 +483,7 @@ int s3enc_create(const s3enc_config* cfg, const s3enc_tensor* tensors, int32_t n
         UP(upload_f32(e->head_b2, t));
     }
 #undef GET
+#undef UPW
 #undef UP
     for (int i = 0; i < s3enc_encoder::RING; ++i) {
         if (hipEventCreateWithFlags(&e->slot_ev[i], hipEventDisableTiming) != hipSuccess) {
@@ -815,7 +835,12 @@ int forward_body(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
             g.out32 = (float*)tmp32;
             {
                 Prof pr(e, st, kind, fl, by);
-                HIP_TRY(launch_gemm(dt, wsplit_of(e, g), st));
+                if (x3in) {  // fp32 LayerNorm output of the previous conv -> three-term GEMM (S3ENC_F16X2, see x2_conv_f32_from)
+                    if (!gemm_x3_eligible(g)) return fail("conv layer is not a shape of the three-term GEMM (internal)");
+                    HIP_TRY(launch_gemm(F32, g, st));
+                } else {
+                    HIP_TRY(launch_gemm(dt, wsplit_of(e, g), st));
+                }
             }
             Prof pr(e, st, "layernorm:conv", 0, (double)B * L[i] * C * (4 + (f32out ? 4 : es)));
             HIP_TRY(launch_layernorm(dt, (const float*)tmp32, (const float*)e->conv[i].lng.p, (const float*)e->conv[i].lnb.p,

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -186,6 +187,67 @@ inline hipError_t upload_gemm_w(DevBuf& d, const std::vector<float>& v, long N, 
     return x2 ? upload_f16_hi_lo(d, v, N, K) : upload_cvt(d, v, dtype);
 }
 
+// S3ENC_F16X2, round 5: the MX-fp4 image of a weight's lo term (lo = w - fp16(w)) for gemm16.hip's MXW K step.  Per row and
+// 32-k block: an E8M0 scale 2^e, e = ceil(log2(max|lo| / 6)) (e2m1's largest magnitude is 6), and 32 e2m1 values lo / 2^e rounded
+// to nearest (ties to the even code), element i of the block in nibble i of its 16 bytes.  data: (N, K/32, 16) bytes, scales:
+// (N, K/32) bytes (bias 127).
+inline unsigned mx_e2m1(float x) {  // |x| <= 6 expected (larger saturates); returns the 4-bit code (sign in bit 3)
+    const unsigned sign = x < 0.f ? 8u : 0u;
+    const float a = x < 0.f ? -x : x;
+    // codes 0..7 = 0, 0.5, 1, 1.5, 2, 3, 4, 6; midpoints 0.25, 0.75, 1.25, 1.75, 2.5, 3.5, 5 go to the even code
+    unsigned c;
+    if (a < 0.25f) c = 0; else if (a == 0.25f) c = 0;
+    else if (a < 0.75f) c = 1; else if (a == 0.75f) c = 2;
+    else if (a < 1.25f) c = 2; else if (a == 1.25f) c = 2;
+    else if (a < 1.75f) c = 3; else if (a == 1.75f) c = 4;
+    else if (a < 2.5f) c = 4; else if (a == 2.5f) c = 4;
+    else if (a < 3.5f) c = 5; else if (a == 3.5f) c = 6;
+    else if (a < 5.f) c = 6; else if (a == 5.f) c = 6;
+    else c = 7;
+    return sign | c;
+}
+inline void pack_mx4_lo(const std::vector<float>& w, long N, long K, std::vector<uint8_t>& data, std::vector<uint8_t>& scales) {
+    const long kb = K / 32;
+    data.assign((size_t)N * kb * 16, 0);
+    scales.assign((size_t)N * kb, 0);
+    for (long n = 0; n < N; ++n)
+        for (long b = 0; b < kb; ++b) {
+            float lo[32], amax = 0.f;
+            for (int i = 0; i < 32; ++i) {
+                const float x = w[(size_t)n * K + b * 32 + i];
+                lo[i] = x - h_from16(h_f16(x), F16);
+                const float a = lo[i] < 0.f ? -lo[i] : lo[i];
+                amax = a > amax ? a : amax;
+            }
+            int ex = -127;
+            if (amax > 0.f) {
+                ex = (int)ceilf(log2f(amax / 6.f));
+                while (ldexpf(6.f, ex) < amax) ++ex;  // (log2f rounding: the scaled maximum must not exceed 6)
+                ex = ex < -127 ? -127 : ex;
+            }
+            const float inv = ldexpf(1.f, -ex);
+            uint8_t* d = &data[((size_t)n * kb + b) * 16];
+            for (int i = 0; i < 32; ++i) d[i >> 1] |= (uint8_t)(mx_e2m1(lo[i] * inv) << ((i & 1) * 4));
+            scales[(size_t)n * kb + b] = (uint8_t)(ex + 127);
+        }
+}
+struct MxImage {
+    DevBuf data, scales;
+    long N = 0, K = 0;
+};
+inline hipError_t upload_mx4_lo(MxImage& m, const std::vector<float>& v, long N, long K) {
+    std::vector<uint8_t> d, s;
+    pack_mx4_lo(v, N, K, d, s);
+    hipError_t e = m.data.ensure(d.size() + 256);
+    if (e != hipSuccess) return e;
+    e = m.scales.ensure(s.size() + 256);
+    if (e != hipSuccess) return e;
+    m.N = N;
+    m.K = K;
+    e = hipMemcpy(m.data.p, d.data(), d.size(), hipMemcpyHostToDevice);
+    return e != hipSuccess ? e : hipMemcpy(m.scales.p, s.data(), s.size(), hipMemcpyHostToDevice);
+}
+
 // S3ENC_F32X3: upload the pair-packed bf16 hi / lo image of an (N, K) fp32 weight (K % 32 == 0, else left empty: that
 // GEMM then runs on the exact kernel)
 inline hipError_t upload_x3(DevBuf& d, const std::vector<float>& v, long N, long K) {
@@ -285,6 +347,9 @@ struct s3enc_encoder {
     std::vector<BlockW> mr_blocks;      // S3ENC_MULTIRES: encoders..., middle_encoder, decoders... (execution order)
     std::vector<AdapterW> mr_adapters;  // downsample_modules[0..R-2], then upsample_modules[0..R-2]
     DevBuf ws_mr;                       // activation workspace of the U-net behind post_extract_proj
+
+    // S3ENC_F16X2: MX-fp4 images of the weights' lo terms, keyed by the device pointer of the [hi | lo] rows they belong to
+    std::map<const void*, std::unique_ptr<MxImage>> mx_images;
 
     Tuning tun;               // s3enc_set_handle_tuning: this handle's own kernel-variant selection ...
     bool has_tuning = false;  // ... in force (for the calling thread) while its forward enqueues kernels
@@ -406,9 +471,18 @@ struct Prof {
     }
 };
 
-// S3ENC_F16X2: every GEMM of the handle runs on its [hi | lo] weight rows
+// S3ENC_F16X2: every GEMM of the handle runs on its [hi | lo] weight rows — with the lo term as an MX-fp4 image where one was
+// packed for exactly this weight (round 5: gemm16.hip MXW; launch_gemm falls back to the two-term loop for other shapes)
 inline GemmParams wsplit_of(const s3enc_encoder* e, GemmParams g) {
     g.wsplit = e->x2 ? 1 : 0;
+    if (e->x2) {
+        auto it = e->mx_images.find(g.W);
+        if (it != e->mx_images.end() && it->second->N == g.N && it->second->K == g.K) {
+            g.W4 = it->second->data.p;
+            g.W4s = it->second->scales.p;
+            g.mxw = 1;
+        }
+    }
     return g;
 }
 

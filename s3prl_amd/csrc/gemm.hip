@@ -337,7 +337,13 @@ hipError_t launch_gemm(int dtype, const GemmParams& p0, hipStream_t stream) {
         if (dtype == F32) return hipErrorInvalidValue;
         if (!p.ldw) p.ldw = 2L * p.K;
         if (((long)p.K * 2) & 127) p.wsplit = 0;  // the lo half must start on a stage boundary: else this GEMM runs on hi alone
+        // the lo term as an MX-fp4 image (round 5): the contraction runs over the hi half only, the image supplies the rest
+        if (p.wsplit && p.mxw && gemm16_mx_eligible(dtype, p)) {
+            p.wsplit = 0;
+            return launch_gemm16_big(dtype, p, stream);
+        }
     }
+    p.mxw = 0;
     if (dtype == F32 && gemm_x3_eligible(p)) {
         if (gemm_tile_eligible(3, p)) return launch_gemm_tile(3, p, stream);
         return launch_gemm_x3(p, stream);

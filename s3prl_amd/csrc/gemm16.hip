@@ -87,13 +87,48 @@ template <> struct Mma16<f16_tag> {
 // 8 bytes hand each lane a contiguous 16-byte piece of its row: the epilogue needs NO LDS transpose (256 KiB written + read per
 // tile before: the largest part of the 7 us a q|k|v tile spent in its epilogue).  Each product a * w and the order in which an
 // accumulator sums them are unchanged — results bit-identical (tests).
-template <typename T, int WTM, int ROWB, int NST, int WPE, int WN, bool PERSIST = false, bool OVL_ = false, bool SWAP = false>
+// dynamic LDS of one workgroup (kernel and launcher agree through this one function)
+constexpr int big_lds_bytes(int BM, int BN, int ROWB, int NST, int WN, bool PERSIST, bool OVL, bool SWAP, bool MXW) {
+    const int stage = (BM + BN) * ROWB + (MXW ? BN * 32 : 0);
+    const int staging = SWAP ? 0 : 2 * WN * (OVL ? 4096 : 8192);  // (SWAP: no LDS in the epilogue)
+    // PERSIST: the epilogue's staging sits behind stage 0, which the next tile's first K step is landing in meanwhile;
+    // OVL: behind BOTH stages (256 x 256: 128 + 32 KiB = all of a CU's LDS)
+    const int body = OVL ? NST * stage + staging : (PERSIST ? (NST * stage > stage + staging ? NST * stage : stage + staging) : NST * stage);
+    return body + (MXW ? 2 * BN * 4 : 0);
+}
+
+// PP (round 5; PERSIST, 2 stages of 4 fragment steps): WHICH fragment steps of a K step carry a wave's DMA pieces depends on the
+// wave's half of the workgroup.  Waves w and w + 4 share a SIMD (and its matrix pipe); an LDS-DMA instruction costs its wave
+// 60-185 issue cycles (MI355X_MICROARCH.md), during which that wave issues no MFMA.  With every wave issuing its 8 pieces behind
+// the reads of steps 0 and 1 (PP = 0) both waves of a SIMD stall at the same time and the pipe idles for ~8 x 100 cycles of a
+// 2048-cycle K step — the whole difference between this loop (1.4 us per step) and a pure MFMA stream (1.0 us: the loop probe,
+// profiles/r03_gemm16_loop_probe.md, priced the pieces at ~55 cycles each with nothing else in the phase).  PP = 1: waves 0-3
+// issue behind steps 0 / 1, waves 4-7 behind steps 2 / 3 — one wave of a SIMD multiplies while its partner issues; PP = 2:
+// steps 0 / 2 and 1 / 3; PP = 3: steps 0 / 1 and 1 / 2 (the late pieces get one more step to land before the stage barrier).
+// A schedule change only: same products, same order per accumulator — bit-identical (tests).
+// MXW (round 5; fp16, the persistent 192 x 256 tile): S3ENC_F16X2's SECOND weight term on the MX pipe.  w = hi + lo with hi = fp16(w);
+// instead of a second fp16 term multiplied in a second pass over K (the `wsplit` loop: twice the MFMAs, A staged twice), lo is an
+// MX-fp4 image — per row and 32 k one E8M0 scale and 32 e2m1 nibbles (GemmParams.W4 / W4s, packed at s3enc_create) — and ONE
+// v_mfma_scale_f32_32x32x64_f8f6f4 per 64 k and accumulator block multiplies it with an MX-fp4 image of A in the same K step as
+// the four fp16 MFMAs (+25 % matrix work instead of +100 %).  The A image is built HERE, on registers: the lane's four fp16
+// fragments of a K step (slot 4 half + q of the row's 128 bytes: k = 32 half + 8 q + j) ARE one 32-k block in natural order, so the
+// block max, the scale and sixteen v_cvt_scalef32_pk_fp4_f16 need no producer and no A-side staging.  W_lo's tile (256 rows x
+// 32 bytes per K step) rides along as one more DMA piece, its scales as a 4-byte piece every second K step.  The products a * lo
+// carry ~2^-4 relative error on a term that is 2^-11 of the weight: 4.8e-5 of weight error against 2.2e-4 for one fp16 term and
+// 4.8e-7 for two (profiles/r04_mx_gemm_lab.md, float64 reference).  K % 128 == 0.
+template <typename T, int WTM, int ROWB, int NST, int WPE, int WN, bool PERSIST = false, bool OVL_ = false, bool SWAP = false, int PP = 0,
+          bool MXW = false>
 __global__ __launch_bounds__(128 * WN, WPE) void gemm16_big_kernel(GemmParams p) {
     constexpr bool OVL = PERSIST && OVL_;
+    static_assert(!MXW || (PERSIST && !OVL_ && NST == 2 && ROWB == 128 && WN == 4 && std::is_same<T, f16_tag>::value),
+                  "MXW: fp16, the persistent 2-stage loop");
+    static_assert(PP == 0 || (PERSIST && NST == 2 && ROWB == 128 && WN == 4), "PP: the persistent 2-stage loop with 4 fragment steps");
     constexpr int NTHR = 128 * WN;  // 2 waves along M x WN along N
     constexpr int BM = 2 * WTM, BN = 64 * WN;
     constexpr int MI = WTM / 32;  // 32-row accumulator blocks per wave
-    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, W4_BYTES = MXW ? BN * 32 : 0, STAGE_BYTES = A_BYTES + B_BYTES + W4_BYTES;
+    constexpr int SCB = BN * 4;  // MXW: scale bytes per buffer — 4 blocks (two K steps) per W row; two buffers behind everything else
+    constexpr int SC_OFF = big_lds_bytes(BM, BN, ROWB, NST, WN, PERSIST, OVL, SWAP, MXW) - (MXW ? 2 * SCB : 0);
     constexpr int SLOTS = ROWB / 16, SMASK = SLOTS - 1;  // 16-byte slots per row per stage
     constexpr int SSH = ROWB == 128 ? 1 : 2;              // swizzle: slot ^= (row >> SSH) & SMASK
     constexpr int RPP = NTHR / SLOTS;                     // rows filled by one pass of the workgroup's waves
@@ -106,6 +141,7 @@ __global__ __launch_bounds__(128 * WN, WPE) void gemm16_big_kernel(GemmParams p)
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wr = wave / WN, wc = wave % WN;
+    const int wr_s = __builtin_amdgcn_readfirstlane(wr);  // (scalar: PP branches on it per fragment step)
     const int half = lane >> 5;
     const int l31 = lane & 31;
 
@@ -154,7 +190,17 @@ __global__ __launch_bounds__(128 * WN, WPE) void gemm16_big_kernel(GemmParams p)
     const int ls = ps ^ ((lr >> SSH) & SMASK);
     const char* a_ptr[NLA];
     const char* w_ptr[NLB];
+    const char *w4_ptr = nullptr, *sc_ptr = nullptr;  // MXW: lane t fills block t & 1 of W_lo row t >> 1; lane t < BN the 4 scale bytes of row t
+    const int kblocks = p.K >> 5;
     auto set_ptrs = [&](int pm0, int pn0, int pb) {
+        if constexpr (MXW) {
+            int r4 = pn0 + (tid >> 1);
+            r4 = r4 < p.N ? r4 : p.N - 1;
+            w4_ptr = (const char*)p.W4 + ((long)r4 * kblocks + (tid & 1)) * 16;
+            int rs = pn0 + tid;
+            rs = rs < p.N ? rs : p.N - 1;
+            sc_ptr = (const char*)p.W4s + (long)rs * kblocks;
+        }
         const char* Ab = (const char*)p.A + (long)pb * p.a_bs * 2;
 #pragma unroll
         for (int i = 0; i < NLA; ++i) {
@@ -176,6 +222,15 @@ __global__ __launch_bounds__(128 * WN, WPE) void gemm16_big_kernel(GemmParams p)
     // M0 (the wave-uniform LDS destination) is written in the same statement that uses it and restored.
     const unsigned lds_base =
         __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem + wave * 1024);
+    const unsigned lds_sc = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem + SC_OFF + wave * 256);
+    auto glds4 = [&](const char* gsrc, unsigned lds_dst) {  // 4 bytes per lane (the MX scales)
+        unsigned keep;
+        asm volatile(
+            "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(gsrc), "s"(lds_dst)
+            : "memory");
+    };
     auto glds16 = [&](const char* gsrc, unsigned lds_dst) {
         unsigned keep;
         asm volatile(
@@ -185,13 +240,19 @@ __global__ __launch_bounds__(128 * WN, WPE) void gemm16_big_kernel(GemmParams p)
             : "memory");
     };
     // piece pc of K-step kt -> LDS stage `stage`: pieces [0, NLA) are A passes, [NLA, NLA + NLB) W passes
-    constexpr int NL = NLA + NLB;
+    constexpr int NL = NLA + NLB + (MXW ? 1 : 0);  // (MXW: + the W_lo tile, one pass)
     auto issue_piece = [&](int pc, int kt, int stage) {
         const long kb = (long)kt * ROWB;
         const long kba = kb >= kbytes ? kb - kbytes : kb;    // (wsplit: the lo half re-reads A from its start; K % 64 == 0)
         const unsigned sa = lds_base + stage * STAGE_BYTES;  // wave-uniform; lane l lands at + l*16
         if (pc < NLA) glds16(a_ptr[pc] + kba, sa + pc * PASS_BYTES);
-        else glds16(w_ptr[pc - NLA] + kb, sa + A_BYTES + (pc - NLA) * PASS_BYTES);
+        else if (pc < NLA + NLB) glds16(w_ptr[pc - NLA] + kb, sa + A_BYTES + (pc - NLA) * PASS_BYTES);
+        else {
+            glds16(w4_ptr + (long)kt * 32, sa + A_BYTES + B_BYTES);
+            // the scales of K steps kt, kt + 1 (blocks 2 kt .. 2 kt + 3) with the even step's last piece: buffer (kt / 2) & 1 was last
+            // read two pairs ago
+            if (!(kt & 1) && wave < BN / 64) glds4(sc_ptr + 2 * kt, lds_sc + ((kt >> 1) & 1) * SCB);
+        }
     };
     auto issue = [&](int kt, int stage) {
 #pragma unroll
@@ -249,6 +310,7 @@ __global__ __launch_bounds__(128 * WN, WPE) void gemm16_big_kernel(GemmParams p)
     constexpr int PPQ = (NL + NQI - 1) / NQI;
     auto compute = [&](int stage, bool pf, int kt_pf, int stage_pf) {
         const char* st = smem + stage * STAGE_BYTES;
+        uint4 keep[MXW ? MI : 1][4];  // MXW: the lane's 32 fp16 values of each row block over the four fragment steps
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int so = ((half * NQ + q) ^ swz) << 4;
@@ -258,15 +320,88 @@ __global__ __launch_bounds__(128 * WN, WPE) void gemm16_big_kernel(GemmParams p)
 #pragma unroll
             for (int i = 0; i < MI; ++i) fa[i] = *(const uint4*)(st + a_row0 + i * 32 * ROWB + so);
             if (pf) {
+                if constexpr (PP == 0) {
 #pragma unroll
-                for (int pc = q * PPQ; pc < (q + 1) * PPQ && pc < NL; ++pc) issue_piece(pc, kt_pf, stage_pf);
+                    for (int pc = q * PPQ; pc < (q + 1) * PPQ && pc < NL; ++pc) issue_piece(pc, kt_pf, stage_pf);
+                } else {
+                    // piece group g (0 / 1) goes out behind the reads of step q0[g] for the first half of the waves, q1[g] for the second
+                    constexpr int q0[2] = {0, PP == 2 ? 2 : 1};
+                    constexpr int q1[2] = {PP == 1 ? 2 : 1, PP == 2 ? 3 : (PP == 1 ? 3 : 2)};
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        const bool mine = (q == q0[g] && q == q1[g]) ? true : (q == q0[g] ? wr_s == 0 : (q == q1[g] ? wr_s != 0 : false));
+                        if (q == q0[g] || q == q1[g]) {
+                            if (mine) {
+#pragma unroll
+                                for (int pc = g * PPQ; pc < (g + 1) * PPQ && pc < NL; ++pc) issue_piece(pc, kt_pf, stage_pf);
+                            }
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                if constexpr (MXW) keep[i][q] = fa[i];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if constexpr (SWAP) Mma16<T>::run(fb[j], fa[i], acc[i][j]);  // lane <-> row m, registers <-> columns n
+                    else Mma16<T>::run(fa[i], fb[j], acc[i][j]);                 // lane <-> column n, registers <-> rows m
+                }
+            }
+        }
+        if constexpr (MXW) {
+            // ---- the second weight term of this K step: acc += mx4(A block) x mx4(W_lo block), 64 k per instruction ----
+            typedef int v8i __attribute__((ext_vector_type(8)));
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            const int kt = kt_pf - 1;
+            const char* sc = smem + SC_OFF + ((kt >> 1) & 1) * SCB + (kt & 1) * 2 + half;
+            uint4 a4[MI], b4[2];
+            int sa[MI], sb[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int row = wc * 64 + j * 32 + l31;
+                b4[j] = *(const uint4*)(st + A_BYTES + B_BYTES + row * 32 + half * 16);
+                sb[j] = (int)(*(const unsigned char*)(sc + row * 4)) * 0x01010101;
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                // block max of the 32 halves (|x| as bit patterns: positive fp16 values order like unsigned integers), the scale
+                // 2^e with max / 2^e <= 6 (e2m1's largest value), sixteen pair conversions
+                unsigned mx = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned d[4] = {keep[i][q].x, keep[i][q].y, keep[i][q].z, keep[i][q].w};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const unsigned a = d[c] & 0x7fff7fffu;
+                        mx = max(mx, max(a & 0xffffu, a >> 16));
+                    }
+                }
+                const float amax = (float)__builtin_bit_cast(_Float16, (unsigned short)mx);
+                int ex = amax > 0.f ? __builtin_amdgcn_frexp_expf(amax * (1.f / 6.f)) : -127;
+                ex = ex < -127 ? -127 : ex;
+                const float scf = __builtin_amdgcn_ldexpf(1.f, ex);
+                unsigned o[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {  // elements 8 q .. 8 q + 7 of the block -> dword q
+                    unsigned w_ = 0;
+                    w_ = __builtin_amdgcn_cvt_scalef32_pk_fp4_f16(w_, __builtin_bit_cast(h2, keep[i][q].x), scf, 0);
+                    w_ = __builtin_amdgcn_cvt_scalef32_pk_fp4_f16(w_, __builtin_bit_cast(h2, keep[i][q].y), scf, 1);
+                    w_ = __builtin_amdgcn_cvt_scalef32_pk_fp4_f16(w_, __builtin_bit_cast(h2, keep[i][q].z), scf, 2);
+                    w_ = __builtin_amdgcn_cvt_scalef32_pk_fp4_f16(w_, __builtin_bit_cast(h2, keep[i][q].w), scf, 3);
+                    o[q] = w_;
+                }
+                a4[i] = make_uint4(o[0], o[1], o[2], o[3]);
+                sa[i] = (ex + 127) * 0x01010101;
             }
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    if constexpr (SWAP) Mma16<T>::run(fb[j], fa[i], acc[i][j]);  // lane <-> row m, registers <-> columns n
-                    else Mma16<T>::run(fa[i], fb[j], acc[i][j]);                 // lane <-> column n, registers <-> rows m
+                    const v8i av = {(int)a4[i].x, (int)a4[i].y, (int)a4[i].z, (int)a4[i].w, 0, 0, 0, 0};
+                    const v8i bv = {(int)b4[j].x, (int)b4[j].y, (int)b4[j].z, (int)b4[j].w, 0, 0, 0, 0};
+                    if constexpr (SWAP) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(bv, av, acc[i][j], 4, 4, 0, sb[j], 0, sa[i]);
+                    else acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, acc[i][j], 4, 4, 0, sa[i], 0, sb[j]);
                 }
         }
     };
@@ -600,20 +735,17 @@ __global__ __launch_bounds__(128 * WN, WPE) void gemm16_big_kernel(GemmParams p)
     }
 }
 
-template <typename T, int WTM, int ROWB, int NST, int WPE, int WN = 4, bool PERSIST = false, bool OVL_ = false, bool SWAP = false>
+template <typename T, int WTM, int ROWB, int NST, int WPE, int WN = 4, bool PERSIST = false, bool OVL_ = false, bool SWAP = false, int PP = 0,
+          bool MXW = false>
 hipError_t big_go(const GemmParams& p, hipStream_t stream) {
     constexpr int BM = 2 * WTM, BN = 64 * WN, NTHR = 128 * WN;
     constexpr bool OVL = PERSIST && OVL_;
-    constexpr int stage = (BM + BN) * ROWB, staging = SWAP ? 0 : 2 * WN * (OVL ? 4096 : 8192);  // (SWAP: no LDS in the epilogue)
-    // PERSIST: the epilogue's staging sits behind stage 0, which the next tile's first K step is landing in meanwhile;
-    // OVL: behind BOTH stages (256 x 256: 128 + 32 KiB = all of a CU's LDS)
-    constexpr int lds = OVL ? NST * stage + staging : (PERSIST ? (NST * stage > stage + staging ? NST * stage : stage + staging) : NST * stage);
+    constexpr int lds = big_lds_bytes(BM, BN, ROWB, NST, WN, PERSIST, OVL, SWAP, MXW);
     static_assert(!OVL || NST == 2, "OVL is written for the 2-stage pipeline");
-    static_assert(lds >= staging, "epilogue staging must fit");
     static_assert(!SWAP || PERSIST, "SWAP is instantiated for the persistent loop only");
     static_assert(lds * (WPE * 4 * 64 / NTHR) <= 160 * 1024, "workgroups per CU x LDS");
-    auto kern = gemm16_big_kernel<T, WTM, ROWB, NST, WPE, WN, PERSIST, OVL_, SWAP>;
-    hipError_t e = ensure_dynamic_lds<gemm16_big_kernel<T, WTM, ROWB, NST, WPE, WN, PERSIST, OVL_, SWAP>>(lds);
+    auto kern = gemm16_big_kernel<T, WTM, ROWB, NST, WPE, WN, PERSIST, OVL_, SWAP, PP, MXW>;
+    hipError_t e = ensure_dynamic_lds<gemm16_big_kernel<T, WTM, ROWB, NST, WPE, WN, PERSIST, OVL_, SWAP, PP, MXW>>(lds);
     if (e != hipSuccess) return e;
     long tiles = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.batches;
     if (PERSIST) {
@@ -651,6 +783,24 @@ hipError_t big_mode(int mode, const GemmParams& p, hipStream_t stream) {
                                     !(p.o_bs & 7) && !((uintptr_t)p.out16 & 15) && !((uintptr_t)p.bias & 15);
             const bool rows_ok = rows_legal && (mode >= 9 || (mode == 7 && p.act != 0 && tuning().gemm16_rows != 0));
             const bool ovl = mode == 8 || mode == 10;
+            if constexpr (std::is_same<T, f16_tag>::value) {
+                if (p.mxw) {  // S3ENC_F16X2, second weight term on the MX pipe: the 192-row tile (its A-image registers fit beside 96 accumulators)
+                    return rows_ok ? big_go<T, 96, 128, 2, 2, 4, true, false, true, 0, true>(p, stream)
+                                   : big_go<T, 96, 128, 2, 2, 4, true, false, false, 0, true>(p, stream);
+                }
+            }
+            if (!ovl && tuning().gemm16_pp) {  // DMA pieces placed per wave half (see PP above)
+                const int pp = tuning().gemm16_pp;
+#define S3_PP_GO(PPV)                                                                                                              \
+    return rows_ok ? (small ? big_go<T, 96, 128, 2, 2, 4, true, false, true, PPV>(p, stream) : big_go<T, 128, 128, 2, 2, 4, true, false, true, PPV>(p, stream)) \
+                   : (small ? big_go<T, 96, 128, 2, 2, 4, true, false, false, PPV>(p, stream) : big_go<T, 128, 128, 2, 2, 4, true, false, false, PPV>(p, stream))
+                if (pp == 1) { S3_PP_GO(1); }
+#ifdef S3_GEMM_PP_LAB
+                if (pp == 2) { S3_PP_GO(2); }
+                if (pp == 3) { S3_PP_GO(3); }
+#endif
+#undef S3_PP_GO
+            }
             if (rows_ok) {
                 if (ovl) return small ? big_go<T, 96, 128, 2, 2, 4, true, true, true>(p, stream) : big_go<T, 128, 128, 2, 2, 4, true, true, true>(p, stream);
                 return small ? big_go<T, 96, 128, 2, 2, 4, true, false, true>(p, stream) : big_go<T, 128, 128, 2, 2, 4, true, false, true>(p, stream);
@@ -682,8 +832,14 @@ bool gemm16_big_eligible(int dtype, const GemmParams& p) {
     return p.N >= 128;
 }
 
+bool gemm16_mx_eligible(int dtype, const GemmParams& p) {
+    return dtype == F16 && p.W4 && p.W4s && !(p.K & 127) && !((uintptr_t)p.W4 & 15) && !((uintptr_t)p.W4s & 3) && gemm16_big_eligible(dtype, p) &&
+           tuning().gemm16_mx != 0 && tuning().gemm16_big != 0;
+}
+
 hipError_t launch_gemm16_big(int dtype, const GemmParams& p, hipStream_t stream) {
-    int mode = tuning().gemm16_big;  // 0 off, 3 = choose by shape, 1 / 2 / 4 / 5 / 6 = force one configuration (see big_mode)
+    int mode = tuning().gemm16_big;
+    if (p.mxw) mode = 7;  // (the MX K step lives in the persistent loop)  // 0 off, 3 = choose by shape, 1 / 2 / 4 / 5 / 6 = force one configuration (see big_mode)
     if (mode == 3) {
         // measured on MI355X (tools/gemm_bench.py, profiles/r02_gemm16_variants.md, and in the full forward with
         // `bench.py --tune gemm16_big=1|4`): with 16-byte stores in the 16-bit epilogues the one-workgroup-per-CU 256x256 /

@@ -32,6 +32,10 @@ struct Tuning {
     int gemm32_big = 1;    // gemmt.hip, fp32: 0 off, 1 = tile height by shape, 2..5 = force 256 / 192 / 128 / 64 rows
     int gemm_x3_tile = 1;  // gemmt.hip, S3ENC_F32X3: 0 off, 1 = only the shapes with few tiles, 2..5 = force a height
     int gemm16_big = 3;    // gemm16.hip: 0 off, 3 = choose by shape, 1 / 2 / 4 / 5 / 6 / 7 = force one configuration
+    int gemm16_pp = 0;     // gemm16.hip, persistent loop: 0 = every wave issues its LDS-DMA pieces behind fragment steps 0 / 1;
+                           // 1 = waves 4-7 behind steps 2 / 3 instead (one wave of a SIMD multiplies while its partner issues)
+    int gemm16_mx = 1;     // S3ENC_F16X2: 1 = the second weight term as an MX-fp4 image on the scaled-MFMA pipe where the shape allows
+                           // (gemm16.hip MXW: 1.13-1.25x on the two-term K loops at 4.8e-5 weight error), 0 = two fp16 terms everywhere
     int gemm16_rows = 1;   // gemm16.hip: 1 = GELU epilogues with a 16-bit output take the row-per-lane (no LDS) form, 0 = never
     int attn_lds_pad = 0;  // 16-bit attention occupancy probe
     int conv0_nt = 1;      // frontend.hip, fp32 output: 1 = non-temporal row stores (the 2 GB activation streams past the caches:
@@ -83,7 +87,15 @@ struct GemmParams {
     //   sum_k a[k] * hi[k] + sum_k a[k] * lo[k]   — the weights' rounding error disappears at twice the matrix cost
     long ldw = 0;
     int wsplit = 0;
+    // S3ENC_F16X2, round 5: the lo term as an MX-fp4 image — W4: (N, K/32, 16 bytes) e2m1 nibbles, element e of a block in nibble e;
+    // W4s: (N, K/32) E8M0 scale bytes; mxw: run the contraction over the hi half of the [hi | lo] rows + this image (gemm16.hip, MXW)
+    // instead of over both halves.  Set by the engine when the image exists; launch_gemm falls back to `wsplit` when the shape is
+    // not the MX kernel's (gemm16_mx_eligible).
+    const void* W4 = nullptr;
+    const void* W4s = nullptr;
+    int mxw = 0;
 };
+bool gemm16_mx_eligible(int dtype, const GemmParams& p);
 // gemm_x3.hip: fp32-class GEMM from three bf16 MFMAs per product (opt-in compute mode S3ENC_F32X3)
 bool gemm_x3_eligible(const GemmParams& p);
 hipError_t launch_gemm_x3(const GemmParams& p, hipStream_t stream);

@@ -18,7 +18,8 @@ int tuning_set(Tuning& t, const char* key, int value, const char** err) {
         {"gemm32_big", &Tuning::gemm32_big, 0, 5},           {"gemm_x3_tile", &Tuning::gemm_x3_tile, 0, 5},
         {"gemm16_big", &Tuning::gemm16_big, 0, 10},          {"gemm16_rows", &Tuning::gemm16_rows, 0, 1},
         {"attn_lds_pad", &Tuning::attn_lds_pad, 0, 48 * 1024}, {"conv0_nt", &Tuning::conv0_nt, 0, 1},
-        {"ws_inplace", &Tuning::ws_inplace, 0, 1},
+        {"ws_inplace", &Tuning::ws_inplace, 0, 1},           {"gemm16_pp", &Tuning::gemm16_pp, 0, 3},
+        {"gemm16_mx", &Tuning::gemm16_mx, 0, 1},
         {"x3_pack_cache", &Tuning::x3_pack_cache, 0, 1},     {"gelu32", &Tuning::gelu32, 0, 1},
     };
     static thread_local char msg[160];
@@ -84,6 +85,24 @@ int s3enc_op_gemm(int32_t dtype, const void* A, int64_t lda, int64_t a_batch_str
     if (dtype == 4) {  // S3ENC_F16X2: fp16 A, W given as (N, 2K) fp16 rows [hi(K) | lo(K)] — the contraction runs over both
         g.wsplit = 1;
         HIP_TRY(launch_gemm(F16, g, (hipStream_t)stream));
+        return 0;
+    }
+    if (dtype == 5) {  // S3ENC_F16X2 with the lo term on the MX pipe (test / lab entry): fp16 A, W given as FP32 (N, K) on the device;
+                       // the [hi | lo] rows and the MX-fp4 image are packed here exactly as s3enc_create packs them
+        std::vector<float> hw((size_t)N * K);
+        HIP_TRY(hipMemcpy(hw.data(), W, hw.size() * 4, hipMemcpyDeviceToHost));
+        DevBuf w2;
+        MxImage img;
+        HIP_TRY(upload_gemm_w(w2, hw, N, K, F16, true));
+        HIP_TRY(upload_mx4_lo(img, hw, N, K));
+        g.W = w2.p;
+        g.wsplit = 1;
+        g.W4 = img.data.p;
+        g.W4s = img.scales.p;
+        g.mxw = 1;
+        if (!gemm16_mx_eligible(F16, g)) return fail("s3enc_op_gemm: shape / alignment not eligible for the MX second-term kernel (K % 128, N >= 128, 16-byte rows)");
+        HIP_TRY(launch_gemm(F16, g, (hipStream_t)stream));
+        HIP_TRY(hipStreamSynchronize((hipStream_t)stream));  // the packed images are freed on return
         return 0;
     }
     if (dtype == 3) {  // S3ENC_F32X3: fp32 operands; W is split into its pair-packed bf16 hi / lo image here

@@ -532,3 +532,33 @@ def test_status_poll_never_blocks():
         enc.forward(dev)
     assert enc.status(wait=True) == 0
     enc.close()
+
+
+@pytest.mark.parametrize("name", ["hubert_base_pseudo", "hubert_base_pl", "wav2vec2_base_pl", "hubert_large_pl", "wavlm_large_pl",
+                                  "data2vec_base_pseudo", "hubert_base_10s_pl"])
+def test_fp16x2_mx_second_term_keeps_the_mode_inside_its_tolerance(name, golden_loader):
+    """Round 5: the lo weight term of conv1 / q|k|v / fc1 / fc2 as an MX-fp4 image (tuning key gemm16_mx = 1, the default) against
+    two fp16 terms (0): 4.8e-5 of weight error per GEMM instead of 5e-7 must leave every fixture inside 1e-3 and within 1e-4 of the
+    two-term result's error; run-to-run bit-identical."""
+    from s3prl_amd import _lib
+
+    meta, cfg, weights, wavs, golden, _ = golden_loader(name)
+    ts, cs = meta["t_stride"], meta["c_stride"]
+    lib = _lib.load()
+    errs, outs = {}, {}
+    try:
+        for mx in (1, 0):
+            _lib.check(lib.s3enc_set_tuning(b"gemm16_mx", mx))
+            enc = _encoder(cfg, weights, dtype="fp16x2")
+            hs = _run(enc, wavs)
+            if mx:
+                assert np.array_equal(hs, _run(enc, wavs)), "not run-to-run bit-identical"
+            assert np.isfinite(hs).all()
+            errs[mx] = max(O.rel_err(hs[l][:, ::ts, ::cs], golden[l]) for l in range(len(golden)))
+            outs[mx] = hs
+            enc.close()
+    finally:
+        _lib.check(lib.s3enc_set_tuning(b"gemm16_mx", 1))
+    assert not np.array_equal(outs[0], outs[1]), "the tuning key selected nothing: both runs took the same kernels"
+    assert errs[1] < 1e-3, f"{name}: fp16x2 with the MX second term {errs[1]:.3e}"
+    assert errs[1] < errs[0] + 1e-4, f"{name}: MX second term {errs[1]:.3e} vs two fp16 terms {errs[0]:.3e}"

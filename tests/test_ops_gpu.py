@@ -246,6 +246,62 @@ def test_gemm_f16x2_two_term_weights(shape):
     assert O.rel_err(out1.cpu().numpy(), y) > 20 * err
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(1, 4000, 2304, 768, 0, False, True), (1, 3000, 3072, 768, 1, False, True), (2, 1500, 768, 3072, 0, True, False),
+                                   (1, 9000, 512, 1536, 1, False, False), (1, 99, 768, 768, 0, False, True), (3, 333, 520, 256, 1, False, True),
+                                   (1, 700, 1024, 128, 0, True, False)])
+def test_gemm_f16x2_mx_second_term(shape):
+    """Round 5: S3ENC_F16X2's lo weight term as an MX-fp4 image on the scaled-MFMA pipe (gemm16.hip MXW; op code 5 packs the images
+    exactly as s3enc_create does).  Against the float64 product with the UNROUNDED weights, on fp16-exact activations with outlier
+    channels and heavy-tailed weights: the MX term must remove most of the one-term weight error (measured 4.8e-5 vs 2.2e-4,
+    profiles/r04_mx_gemm_lab.md; two fp16 terms: 5e-7) on every epilogue the mode uses — 16-bit out plain / GELU (row-per-lane
+    form), fp32 out + residual, fp32 out + GELU — on ragged edges, batches and a 99-row product; and be run-to-run bit-identical."""
+    torch = _torch()
+    from s3prl_amd import _lib
+
+    lib = _lib.load()
+    batches, M, N, K, act, use_res, out16 = shape
+    rng = np.random.default_rng(zlib.crc32(repr(shape).encode()))
+    A = rng.standard_normal((batches, M, K)).astype(np.float32)
+    A[..., ::193] *= 50.0                                                   # a few outlier channels
+    A = _round(A, "fp16")
+    W = (rng.standard_t(4.0, size=(N, K)) / np.sqrt(2.0 * K)).astype(np.float32)  # heavy-tailed
+    bias = rng.standard_normal(N).astype(np.float32)
+    res = rng.standard_normal((batches, M, N)).astype(np.float32)
+
+    def ref(Wm):
+        y = A.astype(np.float64) @ Wm.astype(np.float64).T + bias
+        if act:
+            y = O.gelu(y)
+        return y + res if use_res else y
+
+    y = ref(W)
+    y_hi = ref(W.astype(np.float16).astype(np.float32))                    # what one fp16 term computes
+    one_term = O.rel_err(y_hi, y)
+    dA, dW, dbias, dres = _dev(A, "fp16"), _dev(W), _dev(bias), _dev(res)
+
+    def run():
+        o32 = None if out16 else torch.full((batches, M, N), float("nan"), device="cuda")
+        o16 = torch.full((batches, M, N), float("nan"), device="cuda").half() if out16 else None
+        rc = lib.s3enc_op_gemm(5, _ptr(dA), K, M * K, _ptr(dW), _ptr(dbias), M, N, K, batches, act, _ptr(dres) if use_res else None, None,
+                               _ptr(o32) if o32 is not None else None, _ptr(o16) if o16 is not None else None, N, M * N, None)
+        _lib.check(rc, "s3enc_op_gemm f16x2 + mx")
+        torch.cuda.synchronize()
+        return o16 if out16 else o32
+
+    out = run()
+    assert torch.equal(out, run()), "not run-to-run bit-identical"
+    got = out.float().cpu().numpy()
+    assert np.isfinite(got).all()
+    if out16:  # the output's own fp16 rounding (2.8e-4) hides the weights' error: a loose bound on the fp16 grid (the fp32-output
+               # shapes carry the accuracy claim)
+        err = O.rel_err(got, y.astype(np.float16).astype(np.float64))
+        assert err < 3e-4, f"mx second term {shape}: rel-err on the fp16 grid {err:.3e}"
+    else:
+        err = O.rel_err(got, y)
+        assert err < 8e-5 and err < 0.35 * one_term, f"mx second term {shape}: rel-err {err:.3e}, one fp16 term {one_term:.3e}"
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16", "fp32x3"])
 @pytest.mark.parametrize("T,rel", [(33, False), (200, False), (149, 200), (499, False), (300, 40), (749, 800)])
 def test_attention(dtype, T, rel):
@@ -626,6 +682,7 @@ def test_gemm16_persistent_tile_loop_is_bit_identical(dtype, shape):
     torch = _torch()
     from s3prl_amd import _lib
 
+    MODES, PP_DEFAULT = (1, 7, 8, 9, 10, 107, 109), 0
     lib = _lib.load()
     nb, M, N, K, act, use_res, use_lim, out16 = shape
     code = {"bf16": 1, "fp16": 2}[dtype]
@@ -638,9 +695,12 @@ def test_gemm16_persistent_tile_loop_is_bit_identical(dtype, shape):
     lim = torch.tensor([M - 300 * (b + 1) for b in range(nb)], dtype=torch.int32, device="cuda") if use_lim else None
     outs = []
     try:
-        for mode in (1, 7, 8, 9, 10):  # 8: + the epilogue's stores draining under the next tile (OVL); 9: + the row-per-lane
-                                       # epilogue without LDS (SWAP) where the epilogue is 16-bit-only; 10: both
-            _lib.check(lib.s3enc_set_tuning(b"gemm16_big", mode))
+        # 8: + the epilogue's stores draining under the next tile (OVL); 9: + the row-per-lane epilogue without LDS (SWAP) where the
+        # epilogue is 16-bit-only; 10: both; 107 / 109 (round 5): modes 7 / 9 with gemm16_pp = 1 — the second half of the waves
+        # issues its LDS-DMA pieces two fragment steps later than the first (a schedule change only)
+        for mode in MODES:
+            _lib.check(lib.s3enc_set_tuning(b"gemm16_big", mode % 100))
+            _lib.check(lib.s3enc_set_tuning(b"gemm16_pp", mode // 100))
             o32 = None if out16 else torch.full((nb * M * N,), float("nan"), device="cuda")
             o16 = torch.full((nb * M * N,), float("nan"), device="cuda").to(tdt) if out16 else None
             _lib.check(lib.s3enc_op_gemm(code, _ptr(A), K, M * K, _ptr(W), _ptr(bias), M, N, K, nb, act, _ptr(res) if use_res else None,
@@ -650,8 +710,9 @@ def test_gemm16_persistent_tile_loop_is_bit_identical(dtype, shape):
             outs.append(o16 if out16 else o32)
     finally:
         _lib.check(lib.s3enc_set_tuning(b"gemm16_big", 3))
+        _lib.check(lib.s3enc_set_tuning(b"gemm16_pp", PP_DEFAULT))
     assert torch.isfinite(outs[0].float()).all()
-    for mode, o in zip((7, 8, 9, 10), outs[1:]):
+    for mode, o in zip(MODES[1:], outs[1:]):
         assert torch.equal(outs[0], o), f"gemm16_big = {mode} differs from one tile per workgroup"
     # and the product itself, on a slice of rows of the first batch
     rows = slice(0, 512)

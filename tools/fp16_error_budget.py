@@ -56,6 +56,9 @@ def run(cfg, W, wavs, rounded):
     D = x.shape[-1]
     dh = D // H
     hidden = []
+    # WavLM: the bucketed relative-position bias (layer 0's table, reused by every layer) and the gate computed from the
+    # attention's input — both fp32 in the HIP path (the gate from the LayerNorm kernel's registers), so never rounded here
+    pos_bias = O.rel_pos_bias(cfg, W, T, dt) if getattr(cfg, "relative_position_embedding", False) else None
     for l in range(cfg.encoder_layers):
         hidden.append(x)
         p = f"encoder.layers.{l}"
@@ -63,6 +66,7 @@ def run(cfg, W, wavs, rounded):
         ln2 = (W[f"{p}.final_layer_norm.weight"], W[f"{p}.final_layer_norm.bias"])
 
         def attn(a):
+            a_exact = a
             a = rd("ln_out", a)
             q = (a @ W[f"{p}.self_attn.q_proj.weight"].T + W[f"{p}.self_attn.q_proj.bias"]) * dh ** -0.5
             k = a @ W[f"{p}.self_attn.k_proj.weight"].T + W[f"{p}.self_attn.k_proj.bias"]
@@ -70,6 +74,15 @@ def run(cfg, W, wavs, rounded):
             sp = lambda t: t.reshape(B, T, H, dh).transpose(0, 2, 1, 3)
             q, k, v = sp(rd("q", q)), sp(rd("k", k)), sp(rd("v", v))
             s = q @ k.transpose(0, 1, 3, 2)
+            if pos_bias is not None:
+                bias = pos_bias[None]
+                if cfg.gru_rel_pos:
+                    xh = a_exact.reshape(B, T, H, dh).transpose(0, 2, 1, 3)
+                    gl = xh @ W[f"{p}.self_attn.grep_linear.weight"].T + W[f"{p}.self_attn.grep_linear.bias"]
+                    gl = gl.reshape(B, H, T, 2, 4).sum(-1)
+                    gate = 1.0 / (1.0 + np.exp(-gl))
+                    bias = (gate[..., 0:1] * (gate[..., 1:2] * W[f"{p}.self_attn.grep_a"].reshape(1, H, 1, 1) - 1.0) + 2.0) * bias
+                s = s + bias
             for b in range(B):
                 s[b, :, :, valid[b]:] = -np.inf
             s = s - s.max(-1, keepdims=True)

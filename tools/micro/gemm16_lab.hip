@@ -61,6 +61,13 @@ static int compare(int argc, char** argv) {
         CK(hipMalloc(&o32, mn * 4));
         CK(hipMalloc(&res, mn * 4));
         CK(hipMalloc(&bias, sh.N * 4));
+        unsigned char *w4 = nullptr, *w4s = nullptr;  // cmpx, columns >= 1000: the lo term as an MX-fp4 image (timing: random nibbles, scale 2^-12)
+        if (split) {
+            CK(hipMalloc(&w4, (long)sh.N * sh.K / 2 + 256));
+            CK(hipMalloc(&w4s, (long)sh.N * sh.K / 32 + 256));
+            fill16<<<2048, 256, 0, st>>>((unsigned short*)w4, (long)sh.N * sh.K / 4, 3u, 1.0f);
+            CK(hipMemsetAsync(w4s, 115, (long)sh.N * sh.K / 32, st));
+        }
         fill16<<<2048, 256, 0, st>>>(A, (long)sh.M * sh.K, 1u, 1.0f);
         fill16<<<2048, 256, 0, st>>>(W, (long)sh.N * sh.K * (split ? 2 : 1), 2u, 0.05f);
         CK(hipMemsetAsync(bias, 0, sh.N * 4, st));
@@ -75,7 +82,14 @@ static int compare(int argc, char** argv) {
         for (int c = 0; c < nm; ++c) best[c] = 1e30;
         for (int r = 0; r < 4; ++r)
             for (int c = 0; c < nm; ++c) {
-                s3::g_tuning.gemm16_big = modes[c];
+                s3::g_tuning.gemm16_big = modes[c] % 100;  // (column 107 = mode 7 with gemm16_pp = 1, 207: pp = 2, 307: pp = 3)
+                s3::g_tuning.gemm16_pp = (modes[c] / 100) % 10;
+                const bool mx = split && modes[c] >= 1000 && !(sh.K & 127);  // column 1007: cmpx with the MX second term (gemm16.hip MXW)
+                p.wsplit = split && !mx ? 1 : 0;
+                p.ldw = split ? 2L * sh.K : 0;
+                p.mxw = mx ? 1 : 0;
+                p.W4 = w4;
+                p.W4s = w4s;
                 const int dt = split ? s3::F16 : s3::BF16;
                 CK(s3::launch_gemm16_big(dt, p, st));
                 CK(hipEventRecord(e0, st));
@@ -90,6 +104,7 @@ static int compare(int argc, char** argv) {
         for (int c = 0; c < nm; ++c) printf(" %.1f | %.0f |", best[c] * 1e3, 2.0 * sh.M * (double)sh.N * sh.K / best[c] * 1e-9);  // algorithmic FLOPs (fp16x2 runs twice the MFMAs)
         printf("\n");
         fflush(stdout);
+        if (w4) { CK(hipFree(w4)); CK(hipFree(w4s)); }
         CK(hipFree(A)); CK(hipFree(W)); CK(hipFree(o16)); CK(hipFree(o32)); CK(hipFree(res)); CK(hipFree(bias));
     }
     return 0;

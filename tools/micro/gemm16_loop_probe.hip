@@ -7,10 +7,11 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-constexpr int BM = 256, BN = 256, NTHR = 512, PASS_BYTES = NTHR * 16, MI = 4;
+constexpr int BN = 256, NTHR = 512, PASS_BYTES = NTHR * 16;
 constexpr int PANEL_BYTES = 4096;  // bytes of K per row of the source panel: 256 rows x 4 KiB per operand = 1 MiB + 1 MiB, then it wraps
 
 // DMA: 0 none; 1 as gemm16.hip (global_load_lds_dwordx4 from inline asm, M0 saved / set / restored around every instruction, the 8
@@ -21,8 +22,12 @@ constexpr int PANEL_BYTES = 4096;  // bytes of K per row of the source panel: 25
 // ROWB / NST: bytes of K per row and stage, LDS stages (128 / 2 = the product; 64 / 3, 64 / 4 = rings with two / three K steps in
 // flight and counted vmcnt, the pieces spread over the whole step); a_stride / w_stride: byte offset between the panels of
 // consecutive workgroups (0 = shared)
-template <bool LDSREAD, int DMA, bool BARRIER, int ROWB = 128, int NST = 2>
+// MI: 32-row accumulator blocks per wave (4: the 256 x 256 tile, 3: the 192 x 256 one — same W traffic, 3/4 of the MFMAs)
+// PP (round 5, DMA == 1 only): which fragment steps carry a wave's pieces — 0: steps 0 / 1 for every wave; 1: waves 0-3 steps 0 / 1,
+// waves 4-7 (their SIMD partners) steps 2 / 3; 2: 0 / 2 and 1 / 3; 3: 0 / 1 and 1 / 2 (gemm16.hip's PP)
+template <bool LDSREAD, int DMA, bool BARRIER, int ROWB = 128, int NST = 2, int MI = 4, int PP = 0>
 __global__ __launch_bounds__(512, 2) void probe(const char* A, const char* W, float* out, int nk, long a_stride, long w_stride) {
+    constexpr int BM = 64 * MI;
     constexpr int A_BYTES = BM * ROWB, STAGE_BYTES = (BM + BN) * ROWB;
     constexpr int SLOTS = ROWB / 16, SMASK = SLOTS - 1, SSH = ROWB == 128 ? 1 : 2, RPP = NTHR / SLOTS, NLA = BM / RPP, NLB = BN / RPP, NL = NLA + NLB;
     constexpr int NQ = SLOTS / 2, PANEL_STAGES = PANEL_BYTES / ROWB;
@@ -39,7 +44,7 @@ __global__ __launch_bounds__(512, 2) void probe(const char* A, const char* W, fl
 #pragma unroll
     for (int i = 0; i < NLB; ++i) w_ptr[i] = W + (long)(lr + RPP * i) * rowbytes + ls * 16;
     const int swz = (l31 >> SSH) & SMASK;
-    const int a_row0 = (wr * 128 + l31) * ROWB, w_row0 = A_BYTES + (wc * 64 + l31) * ROWB;
+    const int a_row0 = (wr * 32 * MI + l31) * ROWB, w_row0 = A_BYTES + (wc * 64 + l31) * ROWB;
     f32x16 acc[MI][2];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -47,7 +52,7 @@ __global__ __launch_bounds__(512, 2) void probe(const char* A, const char* W, fl
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    for (int o = tid * 16; o < NST * STAGE_BYTES; o += NTHR * 16) *(uint4*)(smem + o) = make_uint4(0x3f803f80u, 0x3f003f00u, 0x3e803e80u, 0x3e003e00u);
+    for (int o = tid * 16; o < NST * STAGE_BYTES; o += NTHR * 16) *(uint4*)(smem + o) = *(const uint4*)(A + (o & 0xfffff));  // the panel's kind of data (constant / random)
     __syncthreads();
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem + wave * 1024);
     auto dma = [&](const char* gsrc, unsigned dst) {
@@ -78,8 +83,20 @@ __global__ __launch_bounds__(512, 2) void probe(const char* A, const char* W, fl
 #pragma unroll
             for (int i = 0; i < MI; ++i) fa[i] = LDSREAD ? *(const uint4*)(st + a_row0 + i * 32 * ROWB + so) : ca;
             if (DMA && pf) {
+                if constexpr (PP == 0) {
 #pragma unroll
-                for (int pc = q * PPQ; pc < (q + 1) * PPQ && pc < NL; ++pc) issue_piece(pc, kt_pf, stage_pf);
+                    for (int pc = q * PPQ; pc < (q + 1) * PPQ && pc < NL; ++pc) issue_piece(pc, kt_pf, stage_pf);
+                } else {
+                    constexpr int q0[2] = {0, PP == 2 ? 2 : 1};
+                    constexpr int q1[2] = {PP == 1 ? 2 : 1, PP == 2 ? 3 : (PP == 1 ? 3 : 2)};
+                    const int wr_s = __builtin_amdgcn_readfirstlane(wr);
+#pragma unroll
+                    for (int g = 0; g < 2; ++g)
+                        if ((q == q0[g] && wr_s == 0) || (q == q1[g] && wr_s != 0)) {
+#pragma unroll
+                            for (int pc = g * PPQ; pc < (g + 1) * PPQ && pc < NL; ++pc) issue_piece(pc, kt_pf, stage_pf);
+                        }
+                }
             }
 #pragma unroll
             for (int i = 0; i < MI; ++i)
@@ -135,7 +152,7 @@ __global__ __launch_bounds__(512, 2) void probe(const char* A, const char* W, fl
 }
 
 template <typename K>
-double run(K kern, int rowb, int nst, int blocks, int nk, const char* A, const char* W, float* d, long a_stride, long w_stride) {
+double run(K kern, int rowb, int nst, int blocks, int nk, const char* A, const char* W, float* d, long a_stride, long w_stride, int BM = 256) {
     const int lds = nst * (BM + BN) * rowb;
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipEvent_t e0, e1;
@@ -157,9 +174,23 @@ double run(K kern, int rowb, int nst, int blocks, int nk, const char* A, const c
     return best;
 }
 
-int main() {
+// Operand data: the chip clocks to its power budget and MFMA power depends on the operand bits toggling — constant panels (the
+// round-3 form of this probe: hipMemset 0x3c) run the same instruction stream at a ~15-20 % higher clock than the random operands of
+// a real product (MI355X_MICROARCH.md, DVFS give-back).  `gemm16_loop_probe random` fills the panels with hashed bf16 values in
+// [-1, 1) — the rows to hold against gemm16_lab, which multiplies random operands.
+__global__ void fill_random(unsigned short* p, long n) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        unsigned x = (unsigned)i * 2654435761u + 12345u;
+        x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+        const float f = ((int)(x & 0xffffff) - 0x800000) * (1.0f / 0x800000);
+        p[i] = (unsigned short)(__float_as_uint(f) >> 16);
+    }
+}
+
+int main(int argc, char** argv) {
+    const bool random = argc > 1 && !strcmp(argv[1], "random");
     const int blocks = 256;
-    const long panel = (long)BM * PANEL_BYTES;  // 1 MiB per operand
+    const long panel = (long)256 * PANEL_BYTES;  // 1 MiB per operand
     char *A, *W;
     float* d;
     if (hipMalloc(&A, panel * blocks) != hipSuccess || hipMalloc(&W, panel * blocks) != hipSuccess || hipMalloc(&d, 64) != hipSuccess) {
@@ -168,6 +199,12 @@ int main() {
     }
     hipMemset(A, 0x3c, panel * blocks);
     hipMemset(W, 0x3c, panel * blocks);
+    if (random) {
+        hipLaunchKernelGGL(fill_random, dim3(4096), dim3(256), 0, 0, (unsigned short*)A, panel * blocks / 2);
+        hipLaunchKernelGGL(fill_random, dim3(4096), dim3(256), 0, 0, (unsigned short*)W, panel * blocks / 2);
+        hipDeviceSynchronize();
+    }
+    printf("operand panels: %s\n\n", random ? "random bf16 in [-1, 1)" : "constant (0x3c3c)");
     printf("| staging of the next stage(s) | source of A / W | LDS fragment reads | drain + barrier per stage | TFLOP/s |\n|---|---|---|---|---:|\n");
 #define ROW(desc, src, rd, bar, L, D, B, RB, NS, as, ws) \
     printf("| %s | %s | %s | %s | %.0f |\n", desc, src, rd, bar, run(probe<L, D, B, RB, NS>, RB, NS, blocks, 384000 / RB, A, W, d, as, ws)); fflush(stdout);
@@ -188,5 +225,30 @@ int main() {
     ROW("ring of 4 x 32 k (three K steps in flight)", "shared / shared", "yes", "yes", true, 1, true, 64, 4, 0, 0)
     ROW("ring of 4 x 32 k", "private / shared", "yes", "yes", true, 1, true, 64, 4, panel, 0)
     ROW("ring of 4 x 32 k", "private / private", "yes", "yes", true, 1, true, 64, 4, panel, panel)
+    // round 5: the same tile as the product's two (256 / 192 rows), and the DMA pieces placed per wave half (PP)
+    printf("\n| tile | staging | source of A / W | TFLOP/s | us per K step (256 workgroups) |\n|---|---|---|---:|---:|\n");
+#define ROW5(desc, src, D, MIv, PPv, as, ws)                                                                                   \
+    {                                                                                                                          \
+        const double tf = run(probe<true, D, true, 128, 2, MIv, PPv>, 128, 2, blocks, 3000, A, W, d, as, ws, 64 * MIv);      \
+        printf("| %d x 256 | %s | %s | %.0f | %.3f |\n", 64 * MIv, desc, src, tf, 256.0 * 2.0 * 64 * MIv * 256 * 64 / tf * 1e-6); \
+        fflush(stdout);                                                                                                       \
+    }
+    ROW5("none", "-", 0, 4, 0, 0, 0)
+    ROW5("PP 0: every wave issues behind steps 0 / 1 (the product, round 4)", "shared / shared", 1, 4, 0, 0, 0)
+    ROW5("PP 1: waves 0-3 behind steps 0 / 1, waves 4-7 behind 2 / 3", "shared / shared", 1, 4, 1, 0, 0)
+    ROW5("PP 2: 0 / 2 and 1 / 3", "shared / shared", 1, 4, 2, 0, 0)
+    ROW5("PP 3: 0 / 1 and 1 / 2", "shared / shared", 1, 4, 3, 0, 0)
+    ROW5("PP 0", "private / shared", 1, 4, 0, panel, 0)
+    ROW5("PP 1", "private / shared", 1, 4, 1, panel, 0)
+    ROW5("PP 3", "private / shared", 1, 4, 3, panel, 0)
+    ROW5("PP 0", "private / private", 1, 4, 0, panel, panel)
+    ROW5("PP 1", "private / private", 1, 4, 1, panel, panel)
+    ROW5("none", "-", 0, 3, 0, 0, 0)
+    ROW5("PP 0", "shared / shared", 1, 3, 0, 0, 0)
+    ROW5("PP 1", "shared / shared", 1, 3, 1, 0, 0)
+    ROW5("PP 2", "shared / shared", 1, 3, 2, 0, 0)
+    ROW5("PP 3", "shared / shared", 1, 3, 3, 0, 0)
+    ROW5("PP 0", "private / shared", 1, 3, 0, panel, 0)
+    ROW5("PP 1", "private / shared", 1, 3, 1, panel, 0)
     return 0;
 }
