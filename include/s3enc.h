@@ -255,11 +255,12 @@ int s3enc_debug_tap(s3enc_handle h, const char* name, float* host_out, int64_t m
  *   "gemm16_rows":  1 (default) = under mode 7 the GELU epilogues with a 16-bit output (conv1-5, fc1) take the row-per-lane form
  *                   (profiles/r04_gemm16_epilogue.md), 0 = never;
  *   "gemm16_pp":    under mode 7 / 9, which fragment steps of a K step carry a wave's LDS-DMA pieces: 0 (default) = steps 0 / 1 for
- *                   every wave, 1 = waves 4-7 (the SIMD partners of waves 0-3) steps 2 / 3 instead — a schedule change only
- *                   (profiles/r05_gemm16_pp.md);
- *   "gemm16_mx":    S3ENC_F16X2 only: 1 (default) = the second weight term of conv1 / q|k|v / fc1 / fc2 as an MX-fp4 image on the
- *                   scaled-MFMA pipe (4.8e-5 of weight error, 1.13-1.25x on those GEMMs), 0 = two fp16 terms everywhere (5e-7) —
- *                   results differ at the 1e-5 level;
+ *                   every wave, non-zero = waves 4-7 (the SIMD partners of waves 0-3) steps 1 / 2 instead — a schedule change only,
+ *                   measured within 1-3 % of the default (profiles/r05_gemm16_loop_probe.md);
+ *   "gemm16_mx":    S3ENC_F16X2 only, bit mask: which GEMMs take their second weight term as an MX-fp4 image on the scaled-MFMA pipe
+ *                   (gemm16.hip MXW: 4.8e-5 of weight error per GEMM instead of 5e-7) where the shape allows — 1 conv1, 2 q|k|v, 4 fc1,
+ *                   8 fc2, 16 = also shapes whose 256-row tiling needs fewer CU-rounds; default 14; 0 = two fp16 terms everywhere.  Results
+ *                   differ at the 1e-5 ... 1e-4 level (profiles/r05_mx_second_term.md);
  *   "conv0_nt":     1 (default) = the fp32 conv0 kernel writes its activation with non-temporal stores, 0 = plain stores;
  *   "ws_inplace":   1 (default) = post-LN layers run LayerNorm 1 and fc2 in place on one fp32 workspace buffer, 0 = two buffers;
  *   "gelu32":       S3ENC_F32 only: 1 = the one-transcendental erf-GELU every mode uses (default; csrc/common.h gelu_fast: as

@@ -187,12 +187,13 @@ int s3enc_create(const s3enc_config* cfg, const s3enc_tensor* tensors, int32_t n
 
     // a GEMM weight in the handle's operand format; S3ENC_F16X2: + the MX-fp4 image of its lo term where gemm16.hip's MXW K step can
     // take it (K % 128 == 0; wsplit_of finds the image by the weight's device pointer)
-#define UPW(buf, vec, N_, K_)                                         \
+#define UPW(buf, vec, N_, K_, KIND)                                   \
     do {                                                              \
         UP(upload_gemm_w(buf, vec, N_, K_, e->dtype, e->x2));         \
         if (e->x2 && !((K_) & 127) && (N_) >= 128) {                  \
             std::unique_ptr<MxImage> img(new MxImage());              \
             UP(upload_mx4_lo(*img, vec, N_, K_));                     \
+            img->kind = KIND;                                         \
             e->mx_images[(buf).p] = std::move(img);                   \
         }                                                             \
     } while (0)
@@ -222,7 +223,7 @@ int s3enc_create(const s3enc_config* cfg, const s3enc_tensor* tensors, int32_t n
             if (e->x2_conv_f32_from && i >= e->x2_conv_f32_from) {
                 UP(upload_gemm_w(e->conv[i].w, t2, C, (long)k * cin, e->dtype, e->x2));  // (read only if the three-term path declines)
             } else {
-                UPW(e->conv[i].w, t2, C, (long)k * cin);
+                UPW(e->conv[i].w, t2, C, (long)k * cin, 1);
             }
             if (e->x3 || (e->x2_conv_f32_from && i >= e->x2_conv_f32_from)) UP(upload_x3(e->conv[i].w3, t2, C, (long)k * cin));
         }
@@ -341,7 +342,7 @@ int s3enc_create(const s3enc_config* cfg, const s3enc_tensor* tensors, int32_t n
             for (long i = 0; i < (long)D * D; ++i) w[(long)s * D * D + i] = t[i] * sc;
             for (int i = 0; i < D; ++i) bb[(long)s * D + i] = t2[i] * sc;
         }
-        UPW(L.wqkv, w, 3L * D, D);
+        UPW(L.wqkv, w, 3L * D, D, 2);
         if (e->x3) UP(upload_x3(L.wqkv3, w, 3L * D, D));
         UP(upload_f32(L.bqkv, bb));
         GET(p + ".self_attn.out_proj.weight", (long)D * D, t);
@@ -354,12 +355,12 @@ int s3enc_create(const s3enc_config* cfg, const s3enc_tensor* tensors, int32_t n
         GET(p + ".self_attn_layer_norm.bias", D, t);
         UP(upload_f32(L.ln1b, t));
         GET(p + ".fc1.weight", (long)F * D, t);
-        UPW(L.w1, t, F, D);
+        UPW(L.w1, t, F, D, 4);
         if (e->x3) UP(upload_x3(L.w13, t, F, D));
         GET(p + ".fc1.bias", F, t);
         UP(upload_f32(L.b1, t));
         GET(p + ".fc2.weight", (long)D * F, t);
-        UPW(L.w2, t, D, F);
+        UPW(L.w2, t, D, F, 8);
         if (e->x3) UP(upload_x3(L.w23, t, D, F));
         GET(p + ".fc2.bias", D, t);
         UP(upload_f32(L.b2, t));

@@ -234,6 +234,7 @@ inline void pack_mx4_lo(const std::vector<float>& w, long N, long K, std::vector
 struct MxImage {
     DevBuf data, scales;
     long N = 0, K = 0;
+    int kind = 0;  // which GEMM of the path the weight belongs to: a bit of the tuning key gemm16_mx (1 conv, 2 q|k|v, 4 fc1, 8 fc2)
 };
 inline hipError_t upload_mx4_lo(MxImage& m, const std::vector<float>& v, long N, long K) {
     std::vector<uint8_t> d, s;
@@ -477,7 +478,7 @@ inline GemmParams wsplit_of(const s3enc_encoder* e, GemmParams g) {
     g.wsplit = e->x2 ? 1 : 0;
     if (e->x2) {
         auto it = e->mx_images.find(g.W);
-        if (it != e->mx_images.end() && it->second->N == g.N && it->second->K == g.K) {
+        if (it != e->mx_images.end() && it->second->N == g.N && it->second->K == g.K && (tuning().gemm16_mx & it->second->kind)) {
             g.W4 = it->second->data.p;
             g.W4s = it->second->scales.p;
             g.mxw = 1;

@@ -794,11 +794,13 @@ hipError_t big_mode(int mode, const GemmParams& p, hipStream_t stream) {
 #define S3_PP_GO(PPV)                                                                                                              \
     return rows_ok ? (small ? big_go<T, 96, 128, 2, 2, 4, true, false, true, PPV>(p, stream) : big_go<T, 128, 128, 2, 2, 4, true, false, true, PPV>(p, stream)) \
                    : (small ? big_go<T, 96, 128, 2, 2, 4, true, false, false, PPV>(p, stream) : big_go<T, 128, 128, 2, 2, 4, true, false, false, PPV>(p, stream))
-                if (pp == 1) { S3_PP_GO(1); }
 #ifdef S3_GEMM_PP_LAB
+                if (pp == 1) { S3_PP_GO(1); }
                 if (pp == 2) { S3_PP_GO(2); }
-                if (pp == 3) { S3_PP_GO(3); }
 #endif
+                // the library builds PP 3 only (any non-zero key): the one placement that did not lose on random operands
+                // (profiles/r05_gemm16_loop_probe.md); the lab binary builds all three
+                S3_PP_GO(3);
 #undef S3_PP_GO
             }
             if (rows_ok) {
@@ -833,8 +835,16 @@ bool gemm16_big_eligible(int dtype, const GemmParams& p) {
 }
 
 bool gemm16_mx_eligible(int dtype, const GemmParams& p) {
-    return dtype == F16 && p.W4 && p.W4s && !(p.K & 127) && !((uintptr_t)p.W4 & 15) && !((uintptr_t)p.W4s & 3) && gemm16_big_eligible(dtype, p) &&
-           tuning().gemm16_mx != 0 && tuning().gemm16_big != 0;
+    if (!(dtype == F16 && p.W4 && p.W4s && !(p.K & 127) && !((uintptr_t)p.W4 & 15) && !((uintptr_t)p.W4s & 3) && gemm16_big_eligible(dtype, p) &&
+          tuning().gemm16_mx != 0 && tuning().gemm16_big != 0))
+        return false;
+    // the MX K step exists for the 192-row tile only (its A-image registers fit beside 96 accumulators, not beside 128): shapes
+    // whose 256-row tiling needs fewer CU-rounds x rows keep the two-term loop (HuBERT-large fc2: one round of 252 tiles against
+    // two of 336 — measured 306 vs 237 us, profiles/r05_mx_second_term.md)
+    const long nt = (p.N + 255) / 256;
+    const long t256 = ((p.M + 255) / 256) * nt * p.batches, t192 = ((p.M + 191) / 192) * nt * p.batches;
+    const long c256 = ((t256 + 255) / 256) * 256, c192 = ((t192 + 255) / 256) * 192;
+    return c192 <= c256 || (tuning().gemm16_mx & 16);  // (bit 4: force, measurements)
 }
 
 hipError_t launch_gemm16_big(int dtype, const GemmParams& p, hipStream_t stream) {

@@ -33,9 +33,13 @@ struct Tuning {
     int gemm_x3_tile = 1;  // gemmt.hip, S3ENC_F32X3: 0 off, 1 = only the shapes with few tiles, 2..5 = force a height
     int gemm16_big = 3;    // gemm16.hip: 0 off, 3 = choose by shape, 1 / 2 / 4 / 5 / 6 / 7 = force one configuration
     int gemm16_pp = 0;     // gemm16.hip, persistent loop: 0 = every wave issues its LDS-DMA pieces behind fragment steps 0 / 1;
-                           // 1 = waves 4-7 behind steps 2 / 3 instead (one wave of a SIMD multiplies while its partner issues)
-    int gemm16_mx = 1;     // S3ENC_F16X2: 1 = the second weight term as an MX-fp4 image on the scaled-MFMA pipe where the shape allows
-                           // (gemm16.hip MXW: 1.13-1.25x on the two-term K loops at 4.8e-5 weight error), 0 = two fp16 terms everywhere
+                           // non-zero = waves 4-7 (the SIMD partners of waves 0-3) behind steps 1 / 2 instead (PP 3; measured
+                           // within +-1-3 % of 0: profiles/r05_gemm16_loop_probe.md — opt-in)
+    int gemm16_mx = 14;    // S3ENC_F16X2, bit mask: which GEMMs take their second weight term as an MX-fp4 image on the scaled-MFMA pipe
+                           // where the shape allows (gemm16.hip MXW) — 1 conv1, 2 q|k|v, 4 fc1, 8 fc2; 0 = two fp16 terms everywhere;
+                           // 16 = also shapes whose 256-row tiling is cheaper (measurements).  Default 14: conv1 stays on two fp16 terms —
+                           // its A operand (conv0's GroupNorm'd output with loud channels) is the one block-scaled fp4 images suit least
+                           // (wav2vec2_base_pl 6.0e-4 with 14, 7.9e-4 with 15: profiles/r05_mx_second_term.md)
     int gemm16_rows = 1;   // gemm16.hip: 1 = GELU epilogues with a 16-bit output take the row-per-lane (no LDS) form, 0 = never
     int attn_lds_pad = 0;  // 16-bit attention occupancy probe
     int conv0_nt = 1;      // frontend.hip, fp32 output: 1 = non-temporal row stores (the 2 GB activation streams past the caches:

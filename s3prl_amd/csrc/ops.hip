@@ -19,7 +19,7 @@ int tuning_set(Tuning& t, const char* key, int value, const char** err) {
         {"gemm16_big", &Tuning::gemm16_big, 0, 10},          {"gemm16_rows", &Tuning::gemm16_rows, 0, 1},
         {"attn_lds_pad", &Tuning::attn_lds_pad, 0, 48 * 1024}, {"conv0_nt", &Tuning::conv0_nt, 0, 1},
         {"ws_inplace", &Tuning::ws_inplace, 0, 1},           {"gemm16_pp", &Tuning::gemm16_pp, 0, 3},
-        {"gemm16_mx", &Tuning::gemm16_mx, 0, 1},
+        {"gemm16_mx", &Tuning::gemm16_mx, 0, 31},
         {"x3_pack_cache", &Tuning::x3_pack_cache, 0, 1},     {"gelu32", &Tuning::gelu32, 0, 1},
     };
     static thread_local char msg[160];
@@ -100,6 +100,9 @@ int s3enc_op_gemm(int32_t dtype, const void* A, int64_t lda, int64_t a_batch_str
         g.W4 = img.data.p;
         g.W4s = img.scales.p;
         g.mxw = 1;
+        Tuning forced = tuning();
+        forced.gemm16_mx = 31;  // every shape the kernel can take (the engine's default also weighs the tile rounds)
+        TuningScope force(&forced);
         if (!gemm16_mx_eligible(F16, g)) return fail("s3enc_op_gemm: shape / alignment not eligible for the MX second-term kernel (K % 128, N >= 128, 16-byte rows)");
         HIP_TRY(launch_gemm(F16, g, (hipStream_t)stream));
         HIP_TRY(hipStreamSynchronize((hipStream_t)stream));  // the packed images are freed on return

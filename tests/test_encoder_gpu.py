@@ -433,7 +433,7 @@ def test_fp32x3_on_pretrained_like_statistics(name, golden_loader):
 
 
 # measured bounds (profiles/r04_parity.md): see DESIGN §5 for what each mode keeps of its synthetic-statistics error
-PL_16BIT_TOL = {"fp16x2": 1e-3, "fp16": 4e-3, "bf16": 3e-2}
+PL_16BIT_TOL = {"fp16x2": 7.5e-4, "fp16": 4e-3, "bf16": 3e-2}  # fp16x2: round 5 (6.6e-4 worst: profiles/r05_parity.md)
 
 
 @pytest.mark.parametrize("dtype", ["fp16x2", "fp16", "bf16"])
@@ -537,9 +537,9 @@ def test_status_poll_never_blocks():
 @pytest.mark.parametrize("name", ["hubert_base_pseudo", "hubert_base_pl", "wav2vec2_base_pl", "hubert_large_pl", "wavlm_large_pl",
                                   "data2vec_base_pseudo", "hubert_base_10s_pl"])
 def test_fp16x2_mx_second_term_keeps_the_mode_inside_its_tolerance(name, golden_loader):
-    """Round 5: the lo weight term of conv1 / q|k|v / fc1 / fc2 as an MX-fp4 image (tuning key gemm16_mx = 1, the default) against
-    two fp16 terms (0): 4.8e-5 of weight error per GEMM instead of 5e-7 must leave every fixture inside 1e-3 and within 1e-4 of the
-    two-term result's error; run-to-run bit-identical."""
+    """Round 5: the lo weight term of q|k|v / fc1 / fc2 as an MX-fp4 image (tuning key gemm16_mx = 14, the default) against two fp16
+    terms (0): 4.8e-5 of weight error per GEMM instead of 5e-7 must leave every fixture inside 7.5e-4 (the mode's bound on the
+    pretrained-like fixtures) and within 1e-4 of the two-term result's error; run-to-run bit-identical."""
     from s3prl_amd import _lib
 
     meta, cfg, weights, wavs, golden, _ = golden_loader(name)
@@ -547,7 +547,7 @@ def test_fp16x2_mx_second_term_keeps_the_mode_inside_its_tolerance(name, golden_
     lib = _lib.load()
     errs, outs = {}, {}
     try:
-        for mx in (1, 0):
+        for mx in (14, 0):
             _lib.check(lib.s3enc_set_tuning(b"gemm16_mx", mx))
             enc = _encoder(cfg, weights, dtype="fp16x2")
             hs = _run(enc, wavs)
@@ -558,7 +558,7 @@ def test_fp16x2_mx_second_term_keeps_the_mode_inside_its_tolerance(name, golden_
             outs[mx] = hs
             enc.close()
     finally:
-        _lib.check(lib.s3enc_set_tuning(b"gemm16_mx", 1))
-    assert not np.array_equal(outs[0], outs[1]), "the tuning key selected nothing: both runs took the same kernels"
-    assert errs[1] < 1e-3, f"{name}: fp16x2 with the MX second term {errs[1]:.3e}"
-    assert errs[1] < errs[0] + 1e-4, f"{name}: MX second term {errs[1]:.3e} vs two fp16 terms {errs[0]:.3e}"
+        _lib.check(lib.s3enc_set_tuning(b"gemm16_mx", 14))
+    assert not np.array_equal(outs[0], outs[14]), "the tuning key selected nothing: both runs took the same kernels"
+    assert errs[14] < 7.5e-4, f"{name}: fp16x2 with the MX second term {errs[14]:.3e}"
+    assert errs[14] < errs[0] + 1e-4, f"{name}: MX second term {errs[14]:.3e} vs two fp16 terms {errs[0]:.3e}"
