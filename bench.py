@@ -148,6 +148,10 @@ def parse_args(argv=None):
     ap.add_argument("--exchange-via", default="torch", choices=["torch", "cabi"],
                     help="who issues the per-layer RCCL all-gathers: torch.distributed (default) or the library's own "
                          "s3enc_comm_* entry points (the path a non-Python binder uses; needs --backend nccl)")
+    ap.add_argument("--steal-cus", type=int, default=0, metavar="K",
+                    help="CU-contention proxy (one-GPU boxes cannot time a real exchange against the compute it overlaps): K idle workgroups "
+                         "of 256 threads hold CU slots on a side stream for the whole timed region, like the channel kernels of a "
+                         "collective would; combine with --tune reserve_cus=K (profiles/r05_cu_contention.md)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baseline leg (the parity leg still runs)")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=INT",
@@ -326,6 +330,19 @@ def main():
                     gather_layers(hs, overlap_events=events, out=gathered, algo=args.exchange_algo)
             return hs
 
+    steal = {"stream": None, "ms": 0.0}
+
+    def occupy():
+        """--steal-cus: one launch of idle workgroups per step on a side stream, a little longer than a step — the side stream stays
+        busy for the whole timed region (a launch queues behind its predecessor), the compute stream never waits for it."""
+        if not args.steal_cus:
+            return
+        from s3prl_amd import _lib
+
+        if steal["stream"] is None:
+            steal["stream"] = torch.cuda.Stream(device=dev)
+        _lib.check(_lib.load().s3enc_debug_occupy_cus(args.steal_cus, 256, steal["ms"], steal["stream"].cuda_stream), "s3enc_debug_occupy_cus")
+
     def timed(k, exchange=True, profile=False):
         """k steps bracketed by barrier + synchronize on both sides; max over ranks."""
         prof_steps = 0
@@ -338,11 +355,18 @@ def main():
             if profile:
                 enc.profile_enable(2 if on else 0)
             prof_steps += int(on)
+            occupy()
             step(exchange)
+        if steal["stream"] is not None:
+            # the compute stream's last step is the end of the timed region; the idle workgroups queued past it are not work
+            torch.cuda.current_stream(dev).synchronize()
+            el_steal = time.perf_counter() - t0
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         el = time.perf_counter() - t0
+        if steal["stream"] is not None:
+            el = el_steal
         if profile:
             enc.profile_enable(False)
         if world > 1:
@@ -355,6 +379,12 @@ def main():
         for _ in range(args.warmup):
             step()
         torch.cuda.synchronize()
+        if args.steal_cus:  # size one occupy launch to ~1.2 undisturbed steps
+            t_w = time.perf_counter()
+            for _ in range(5):
+                step()
+            torch.cuda.synchronize()
+            steal["ms"] = (time.perf_counter() - t_w) / 5 * 1e3 * 1.2
         enc.profile_reset()
         # timed region: HIP events only around the launches of the dominant kernel (the GEMM), and only on every 4th
         # step — an event pair costs a ~5 us bubble on the stream: around all ~290 launches of a forward that is 0.8 ms
@@ -430,6 +460,7 @@ def main():
                 "utterances_per_gpu": B, "global_batch": B * world, "samples": n, "frames_per_utt": T, "parallelism": f"dp{world}",
                 "lengths": "mixed (utt 0 = max, rest randint(16000, max), padding-masked)" if args.mixed else "equal",
                 "gather": gather, "backend": args.backend if world > 1 else None, "rccl": rccl, "devices": devices,
+                **({"steal_cus": args.steal_cus} if args.steal_cus else {}),
             },
             # the reference computes padded frames too, so the path's work is B x F_utt(n_max)
             "path_tflops": round(world * B * flops_per_utt(cfg, n) / (ms_per_step * 1e-3) / 1e12, 2),

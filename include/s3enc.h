@@ -241,6 +241,9 @@ int s3enc_profile_read(s3enc_handle h, s3enc_profile_entry* entries, int32_t max
 /* Copy an intermediate of the LAST forward to the host as fp32 (test hook): the last three conv layers
  * ("conv4".."conv6" for the 7-layer stack), "feat_ln", "proj", "posconv", "qkv0", "attn0".  Synchronises. */
 int s3enc_debug_tap(s3enc_handle h, const char* name, float* host_out, int64_t max_elems, int64_t* n_elems);
+/* Measurement hook (no reference counterpart): `workgroups` x `threads` idle threads that hold their CU slots for `milliseconds` on
+ * `stream` — a stand-in for a collective's channel kernels running beside the encoder (bench.py --steal-cus). */
+int s3enc_debug_occupy_cus(int32_t workgroups, int32_t threads, double milliseconds, void* stream);
 
 /* Process-wide tuning knobs (kernel-variant selection for A/B measurements; results are unchanged, except "gelu32"):
  *   "gemm_variant": gemm.hip's 128x128 kernel: bit 0 = 64-byte K stages (else 128), bit 1 = LDS-DMA staging, bit 2 = no
@@ -261,6 +264,8 @@ int s3enc_debug_tap(s3enc_handle h, const char* name, float* host_out, int64_t m
  *                   (gemm16.hip MXW: 4.8e-5 of weight error per GEMM instead of 5e-7) where the shape allows — 1 conv1, 2 q|k|v, 4 fc1,
  *                   8 fc2, 16 = also shapes whose 256-row tiling needs fewer CU-rounds; default 14; 0 = two fp16 terms everywhere.  Results
  *                   differ at the 1e-5 ... 1e-4 level (profiles/r05_mx_second_term.md);
+ *   "reserve_cus":  CUs the persistent one-workgroup-per-CU GEMM of the 16-bit modes leaves out of its grid (default 0; a measurement
+ *                   knob — leaving CUs to a collective's channel kernels costs more than sharing them: profiles/r05_cu_contention.md);
  *   "conv0_nt":     1 (default) = the fp32 conv0 kernel writes its activation with non-temporal stores, 0 = plain stores;
  *   "ws_inplace":   1 (default) = post-LN layers run LayerNorm 1 and fc2 in place on one fp32 workspace buffer, 0 = two buffers;
  *   "gelu32":       S3ENC_F32 only: 1 = the one-transcendental erf-GELU every mode uses (default; csrc/common.h gelu_fast: as

@@ -749,7 +749,11 @@ hipError_t big_go(const GemmParams& p, hipStream_t stream) {
     if (e != hipSuccess) return e;
     long tiles = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.batches;
     if (PERSIST) {
-        const int cus = device_cus();
+        // `reserve_cus` (measurement knob, default 0): leave CUs out of the grid for somebody else's long-running workgroups (the
+        // channel kernels of a collective).  Measured NOT to pay: foreign workgroups cost +2 %, a smaller grid +20 %
+        // (profiles/r05_cu_contention.md)
+        int cus = device_cus() - tuning().reserve_cus;
+        cus = cus < 8 ? 8 : cus;
         if (tiles > cus) tiles = cus;
     }
     dim3 grid((unsigned)tiles);

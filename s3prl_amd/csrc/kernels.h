@@ -40,6 +40,9 @@ struct Tuning {
                            // 16 = also shapes whose 256-row tiling is cheaper (measurements).  Default 14: conv1 stays on two fp16 terms —
                            // its A operand (conv0's GroupNorm'd output with loud channels) is the one block-scaled fp4 images suit least
                            // (wav2vec2_base_pl 6.0e-4 with 14, 7.9e-4 with 15: profiles/r05_mx_second_term.md)
+    int reserve_cus = 0;   // gemm16.hip, persistent loop: CUs left out of the one-workgroup-per-CU grid.  Measured (profiles/r05_cu_contention.md):
+                           // 8-32 foreign workgroups holding CU slots cost the 16-bit step +2 % whatever their number, while a grid of
+                           // 240 costs +20 % (the tile rounds are tuned to 256 CUs: q|k|v's 756 tiles become four rounds) — keep 0
     int gemm16_rows = 1;   // gemm16.hip: 1 = GELU epilogues with a 16-bit output take the row-per-lane (no LDS) form, 0 = never
     int attn_lds_pad = 0;  // 16-bit attention occupancy probe
     int conv0_nt = 1;      // frontend.hip, fp32 output: 1 = non-temporal row stores (the 2 GB activation streams past the caches:

@@ -19,7 +19,7 @@ int tuning_set(Tuning& t, const char* key, int value, const char** err) {
         {"gemm16_big", &Tuning::gemm16_big, 0, 10},          {"gemm16_rows", &Tuning::gemm16_rows, 0, 1},
         {"attn_lds_pad", &Tuning::attn_lds_pad, 0, 48 * 1024}, {"conv0_nt", &Tuning::conv0_nt, 0, 1},
         {"ws_inplace", &Tuning::ws_inplace, 0, 1},           {"gemm16_pp", &Tuning::gemm16_pp, 0, 3},
-        {"gemm16_mx", &Tuning::gemm16_mx, 0, 31},
+        {"gemm16_mx", &Tuning::gemm16_mx, 0, 31},            {"reserve_cus", &Tuning::reserve_cus, 0, 128},
         {"x3_pack_cache", &Tuning::x3_pack_cache, 0, 1},     {"gelu32", &Tuning::gelu32, 0, 1},
     };
     static thread_local char msg[160];
@@ -140,6 +140,25 @@ int s3enc_op_gemm(int32_t dtype, const void* A, int64_t lda, int64_t a_batch_str
         return 0;
     }
     HIP_TRY(launch_gemm(dtype, g, (hipStream_t)stream));
+    return 0;
+}
+
+// Measurement hook: `workgroups` workgroups of `threads` threads that do nothing but hold their CU slots for `milliseconds` on `stream`
+// — a stand-in for the channel kernels of a collective running beside the encoder (bench.py --steal-cus; there is one GPU per box on
+// this pool, so the real RCCL exchange cannot be timed against the compute it overlaps)
+namespace {
+__global__ void occupy_kernel(long long ticks) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+}  // namespace
+int s3enc_debug_occupy_cus(int32_t workgroups, int32_t threads, double milliseconds, void* stream) {
+    if (workgroups <= 0 || threads <= 0 || threads > 1024 || milliseconds < 0) return fail("s3enc_debug_occupy_cus: bad argument");
+    int dev = 0, khz = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) khz = 100000;  // 100 MHz
+    hipLaunchKernelGGL(occupy_kernel, dim3(workgroups), dim3(threads), 0, (hipStream_t)stream, (long long)(milliseconds * khz));
+    HIP_TRY(hipGetLastError());
     return 0;
 }
 

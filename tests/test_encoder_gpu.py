@@ -447,7 +447,9 @@ def test_16bit_modes_on_pretrained_like_statistics(name, dtype, golden_loader):
     assert np.isfinite(hs).all(), f"{name}/{dtype}: non-finite hidden states"
     ts, cs = meta["t_stride"], meta["c_stride"]
     errs = [O.rel_err(hs[l][:, ::ts, ::cs], golden[l]) for l in range(len(golden))]
-    assert max(errs) < PL_16BIT_TOL[dtype], f"{name}/{dtype}: per-layer rel-err {['%.2e' % e for e in errs]}"
+    # (the tiny fixtures' dimensions are below what the fp16x2 hybrids take — C, D < 128: they keep the path's 1e-3)
+    tol = 1e-3 if dtype == "fp16x2" and name.startswith("tiny_") else PL_16BIT_TOL[dtype]
+    assert max(errs) < tol, f"{name}/{dtype}: per-layer rel-err {['%.2e' % e for e in errs]}"
     enc.close()
 
 
