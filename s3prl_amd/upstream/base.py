@@ -14,7 +14,8 @@ The forward is inference-only (the HIP path has no backward): asking for gradien
 grad at the call, and for the reference's fine-tuning flow (``upstream_trainable``: ``entry.model.train()`` + a forward
 with autograd enabled, downstream/runner.py:258-262,296-301) at ``loss.backward()``: in training mode the states carry an
 autograd node whose backward raises, so an expert that has no parameters is never silently "fine-tuned" as a frozen
-one.  Frozen use (``.eval()`` or ``torch.no_grad()``) is unaffected.  Waveforms on the CPU are
+one.  Frozen use (``.eval()`` or ``torch.no_grad()``) is unaffected, and an expert is CONSTRUCTED in eval mode (it has nothing
+to train): only an explicit ``.train()`` — the runner's, or ``s3prl.nn.S3PRLUpstream.__init__``'s — arms the guard.  Waveforms on the CPU are
 copied to the current GPU, encoded there, and the states are returned on the waveforms' device (that is a transfer,
 not a fallback: without a GPU the call raises) — ``S3PRLUpstream.__init__`` probes every upstream with CPU pseudo
 waveforms (nn/upstream.py:124-126).
@@ -60,6 +61,7 @@ class HipUpstreamExpert(torch.nn.Module):
         self._encoders: Dict[int, HipEncoder] = {}
         # a buffer so that .to(device) / .cuda() of the enclosing model has something to move and report
         self.register_buffer("_device_probe", torch.zeros(1), persistent=False)
+        self.eval()  # nothing to train: `.train()` is the explicit request of a fine-tuning flow (see _guard_backward)
 
     @classmethod
     def from_weights(cls, cfg: EncoderConfig, weights, dtype: str = "fp32"):
@@ -69,7 +71,7 @@ class HipUpstreamExpert(torch.nn.Module):
         assert cfg.family == cls.family
         self.cfg, self._weights, self.dtype, self._encoders = cfg, dict(weights), dtype, {}
         self.register_buffer("_device_probe", torch.zeros(1), persistent=False)
-        return self
+        return self.eval()
 
     def randomize_(self, seed: Optional[int] = None):
         """``S3PRLUpstream(randomize=True)`` (nn/upstream.py:27-35,119-120): re-draw every checkpoint tensor — vectors from

@@ -33,6 +33,7 @@ class UpstreamExpert(HipUpstreamExpert):
         self.dtype = dtype or os.environ.get("S3PRL_AMD_DTYPE", "fp32")
         self._encoders: Dict[int, HipEncoder] = {}
         self.register_buffer("_device_probe", torch.zeros(1), persistent=False)
+        self.eval()
 
     def forward(self, wavs):
         hs = self.encode(wavs)

@@ -144,9 +144,10 @@ def test_fine_tuning_flow_raises_at_backward_instead_of_silently_freezing():
 
     cfg = named_config("tiny_hubert")
     expert = HipUpstreamExpert.from_weights(cfg, synth_weights(cfg, 0))
-    assert list(expert.parameters()) == []
+    assert list(expert.parameters()) == [] and not expert.training   # constructed in eval mode: nothing to train
     slab = torch.zeros(4, 2, 5, 8)
-    expert.train()
+    assert expert._guard_backward(slab) is slab
+    expert.train()                                                    # what the runner's fine-tuning flow does
     guarded = expert._guard_backward(slab)
     assert guarded.requires_grad and torch.equal(guarded, slab)
     with pytest.raises(RuntimeError, match="inference-only"):

@@ -3,10 +3,10 @@
 #   per BASELINE config: PMC passes (-> profiles/traffic.json record) -> bench (its JSON then carries roofline.traffic) ->
 #   rocprofv3 kernel-trace summary; the operand modes of the headline workload; the micro labs; the parity table.
 # Raw rocprof output stays on the box (only the summaries are merged back: gpurun_out is capped at 64 MiB).
-# usage: tools/round_profiles.sh r04        (most important artefacts first: a cut-off run still leaves them)
+# usage: tools/round_profiles.sh r05        (most important artefacts first: a cut-off run still leaves them)
 #        PROFILE_ONLY="fp32 bf16" tools/round_profiles.sh r04   (PMC + rocprof only for the named configurations, bench lines for all)
 set -u
-tag=${1:-r04}
+tag=${1:-r05}
 export TMPDIR=/tmp
 out=gpurun_out/$tag
 mkdir -p $out
@@ -58,7 +58,7 @@ done
 # 4. micro labs (standalone binaries, seconds each)
 for b in gemm32_lab attn_lab gemm16_lab gemm16_loop_probe mx_probe; do [ -x tools/micro/$b ] || echo "tools/micro/$b is not built" >&2; done
 tools/micro/gemm16_lab cmp 7 8 9 10 > $out/gemm16_lab_modes.md 2>&1        # persistent loop / + store overlap / row-per-lane epilogue / both
-tools/micro/gemm16_lab cmpx 7 9 > $out/gemm16_lab_modes_fp16x2.md 2>&1
+tools/micro/gemm16_lab cmpx 7 9 1007 > $out/gemm16_lab_modes_fp16x2.md 2>&1   # (1007: the MX second weight term, forced on every shape)
 tools/micro/gemm16_lab cmp8 7 > $out/gemm16_lab_shared_panels.md 2>&1       # every operand L2-resident: what the memory side costs
 tools/micro/attn_lab > $out/attn_lab.md 2>&1
 tools/micro/mx_probe > $out/mx_probe.md 2>&1
