@@ -156,3 +156,36 @@ def test_fine_tuning_flow_raises_at_backward_instead_of_silently_freezing():
         assert not expert._guard_backward(slab).requires_grad
     expert.eval()
     assert expert._guard_backward(slab) is slab
+
+
+def test_outlier_writer_scaling_touches_only_the_residual_writers():
+    """tools/fp16_cliff.py's knob: rows of fc2 / out_proj (and their biases) on the profile's outlier channels, nothing else."""
+    from s3prl_amd.synth import named_config, outlier_channels, scale_outlier_writers, synth_weights
+
+    cfg = named_config("tiny_hubert_large")
+    w = synth_weights(cfg, 3, "pretrained_like")
+    hot = outlier_channels(cfg, 3)
+    assert len(set(hot.tolist())) == 4 and hot.max() < cfg.encoder_embed_dim
+    w10 = scale_outlier_writers(cfg, w, 3, 10.0)
+    assert set(w10) == set(w)
+    cold = np.setdiff1d(np.arange(cfg.encoder_embed_dim), hot)
+    for name in w:
+        if name.endswith((".fc2.weight", ".out_proj.weight", ".fc2.bias", ".out_proj.bias")):
+            assert np.allclose(w10[name][hot], 10.0 * w[name][hot]) and np.array_equal(w10[name][cold], w[name][cold]), name
+        else:
+            assert w10[name] is w[name], name
+    # the pretrained-like profile made exactly these rows loud in the first place
+    fc2 = w["encoder.layers.0.fc2.weight"]
+    assert np.abs(fc2[hot]).mean() > 10 * np.abs(fc2[cold]).mean()
+
+
+def test_mx_second_term_tuning_key_is_a_bit_mask():
+    """`gemm16_mx` (include/s3enc.h): bit 1 conv1, 2 q|k|v, 4 fc1, 8 fc2, 16 force; default 14.  (The packer and the K step are checked
+    on the GPU against a float64 product: tests/test_ops_gpu.py::test_gemm_f16x2_mx_second_term.)"""
+    from s3prl_amd import _lib
+
+    lib = _lib.load()
+    for mask in (0, 1, 2, 4, 8, 14, 15, 31):
+        _lib.check(lib.s3enc_set_tuning(b"gemm16_mx", mask))
+    assert lib.s3enc_set_tuning(b"gemm16_mx", 32) != 0
+    _lib.check(lib.s3enc_set_tuning(b"gemm16_mx", 14))
