@@ -72,16 +72,45 @@ def csrc_sha16():
     return h.hexdigest()[:16]
 
 
+def device_code_md5():
+    """md5 of the `.hip_fatbin` section of the built s3prl_amd/libs3enc.so — the gfx950 code objects themselves.  The second identity a
+    PMC record carries (round 5): a change to HOST code under csrc/ (a weight packer, an argument check) moves `csrc_sha16` but not the
+    kernels the counters were measured on.  None if the library is not built / not an ELF64 file."""
+    import hashlib
+    import struct
+
+    try:
+        with open(os.path.join(ROOT, "s3prl_amd", "libs3enc.so"), "rb") as f:
+            data = f.read()
+        if data[:4] != b"\x7fELF" or data[4] != 2:
+            return None
+        shoff, = struct.unpack_from("<Q", data, 0x28)
+        shentsize, shnum, shstrndx = struct.unpack_from("<HHH", data, 0x3A)
+        sec = lambda i: struct.unpack_from("<IIQQQQIIQQ", data, shoff + i * shentsize)
+        str_off = sec(shstrndx)[4]
+        for i in range(shnum):
+            name, _type, _flags, _addr, off, size = sec(i)[:6]
+            end = data.index(b"\0", str_off + name)
+            if data[str_off + name:end] == b".hip_fatbin":
+                return hashlib.md5(data[off:off + size]).hexdigest()
+    except (OSError, ValueError, struct.error):
+        pass
+    return None
+
+
 def pmc_traffic(path, model, dtype, batch, secs):
     """HBM-side bytes per launch of the dominant kernel, from the committed PMC passes of this same workload
     (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md §HBM).  Returns (record or None, note or None): a record measured on other
-    kernels than the ones in this tree (its `csrc_sha16` stamp differs, or it carries none) is NOT quoted — the note says so."""
+    kernels than the ones in this tree (its `csrc_sha16` stamp differs and so does its `device_code_md5`, or it carries neither) is NOT
+    quoted — the note says so."""
     try:
         for rec in json.load(open(path)):
             if (rec["model"], rec["dtype"], rec["batch"], rec["secs"]) == (model, dtype, batch, secs):
                 have = csrc_sha16()
                 if rec.get("csrc_sha16") == have:
                     return rec, None
+                if rec.get("device_code_md5") and rec["device_code_md5"] == device_code_md5():
+                    return rec, None  # the sources moved (host code), the code objects the counters were measured on did not
                 return None, (f"profiles/traffic.json holds a record of this workload measured on kernels {rec.get('csrc_sha16', '(unstamped, round <= 3)')}"
                               f"{' at commit ' + rec['commit'] if rec.get('commit') else ''}; this tree's csrc is {have} — stale, not quoted "
                               "(tools/round_profiles.sh re-measures it)")

@@ -220,12 +220,16 @@ inline void pack_mx4_lo(const std::vector<float>& w, long N, long K, std::vector
                 amax = a > amax ? a : amax;
             }
             int ex = -127;
-            if (amax > 0.f) {
+            if (!(amax <= 3.0e38f)) {
+                // a weight outside the fp16 range (hi = inf, lo = -inf) or NaN: the product is non-finite whatever this image says
+                // (the forward's status word reports it); E8M0 0xFF is the format's NaN
+                ex = 128;
+            } else if (amax > 0.f) {
                 ex = (int)ceilf(log2f(amax / 6.f));
-                while (ldexpf(6.f, ex) < amax) ++ex;  // (log2f rounding: the scaled maximum must not exceed 6)
-                ex = ex < -127 ? -127 : ex;
+                while (ex < 127 && ldexpf(6.f, ex) < amax) ++ex;  // (log2f rounding: the scaled maximum must not exceed 6)
+                ex = ex < -127 ? -127 : (ex > 127 ? 127 : ex);
             }
-            const float inv = ldexpf(1.f, -ex);
+            const float inv = ex > 127 ? 0.f : ldexpf(1.f, -ex);
             uint8_t* d = &data[((size_t)n * kb + b) * 16];
             for (int i = 0; i < 32; ++i) d[i >> 1] |= (uint8_t)(mx_e2m1(lo[i] * inv) << ((i & 1) * 4));
             scales[(size_t)n * kb + b] = (uint8_t)(ex + 127);

@@ -71,6 +71,28 @@ def test_stale_traffic_record_is_not_quoted(tmp_path):
     got, note = bench.pmc_traffic(str(path), "hubert_base", "fp32", 32, 10.0)
     assert got["gemm_bytes_per_launch"] == 123 and note is None
     assert bench.pmc_traffic(str(path), "hubert_large", "fp32", 32, 10.0) == (None, None)
+    # round 5: the second identity — the gfx950 code objects of the built library.  A record whose source stamp is stale (host code
+    # under csrc/ changed) is still current when the .hip_fatbin it was measured on is the one this tree builds; any other md5 is not
+    md5 = bench.device_code_md5()
+    assert md5 is not None and len(md5) == 32, "libs3enc.so is built by the CPU suite's first test (build())"
+    path.write_text(json.dumps([dict(rec, csrc_sha16="0" * 16, device_code_md5=md5)]))
+    got, note = bench.pmc_traffic(str(path), "hubert_base", "fp32", 32, 10.0)
+    assert got is not None and note is None
+    path.write_text(json.dumps([dict(rec, csrc_sha16="0" * 16, device_code_md5="f" * 32)]))
+    got, note = bench.pmc_traffic(str(path), "hubert_base", "fp32", 32, 10.0)
+    assert got is None and "stale" in note
+
+
+def test_committed_traffic_records_of_the_headline_workload_are_current():
+    """The default bench line quotes roofline.traffic from profiles/traffic.json: the committed record of the metric's workload must
+    match this tree (by source stamp or by device code), else the driver's line says `traffic: null`."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    rec, note = bench.pmc_traffic(os.path.join(ROOT, "profiles", "traffic.json"), "hubert_base", "fp32", 32, 10.0)
+    assert rec is not None, note
 
 
 def test_fp16_error_budget_tool_runs_on_a_tiny_fixture():

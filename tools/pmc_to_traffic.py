@@ -20,7 +20,7 @@ write = 1024.0 * tot["WRITE_SIZE"][1] / max(1, tot["WRITE_SIZE"][0])
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # csrc_sha16: the identity of the kernels these counters were measured on (bench.py refuses a stale record)
 
-rec = {"model": model, "dtype": dtype, "batch": int(batch), "secs": float(secs), "csrc_sha16": bench.csrc_sha16(),
+rec = {"model": model, "dtype": dtype, "batch": int(batch), "secs": float(secs), "csrc_sha16": bench.csrc_sha16(), "device_code_md5": bench.device_code_md5(),
        "gemm_bytes_per_launch": round(fetch + write), "fetch_bytes_per_launch": round(fetch),
        "write_bytes_per_launch": round(write), "launches_profiled": tot["FETCH_SIZE"][0],
        "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --model {model} --dtype {dtype}` "
