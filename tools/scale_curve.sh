@@ -8,7 +8,7 @@
 # summary at the end is the scaling table (efficiency is computed here only for reading convenience — the driver computes its own).
 # usage: tools/scale_curve.sh [tag] [max_gpus]
 set -u
-tag=${1:-r04}
+tag=${1:-r05}
 maxn=${2:-8}
 out=gpurun_out/${tag}_scale
 mkdir -p $out
@@ -39,6 +39,9 @@ for n in $ns; do
   run weak_fp16x2_n${n}_direct_cabi $n --dtype fp16x2 --steps 100 --warmup 5 --exchange-algo direct --exchange-via cabi
   run weak_fp16x2_n${n}_featurized $n --dtype fp16x2 --steps 100 --warmup 5 --gather featurized
   run weak_fp16x2_n${n}_none $n --dtype fp16x2 --steps 100 --warmup 5 --gather none
+  # the CU side of the exchange against its one-GPU proxy (profiles/r05_cu_contention.md: +2 % for foreign workgroups, +20 % for a
+  # smaller persistent grid): the same run with 16 CUs left out of the 16-bit GEMM's grid
+  run weak_fp16x2_n${n}_direct_reserve16 $n --dtype fp16x2 --steps 100 --warmup 5 --exchange-algo direct --tune reserve_cus=16
 done
 
 python - "$out" <<'PY'
