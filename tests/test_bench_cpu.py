@@ -124,3 +124,39 @@ def test_scale_curve_summary_table(tmp_path):
     out = subprocess.run([sys.executable, "-c", body, str(tmp_path)], capture_output=True, text=True, timeout=60)
     assert out.returncode == 0, out.stderr
     assert "| weak_fp32_n2_direct | 2 | 870000 | 36.0 | 1.98 |" in out.stdout and "weak_fp32_n1" in out.stdout
+
+
+def test_mx_second_term_emulation_on_a_tiny_fixture():
+    """`tools/fp16_error_budget.py mx`: the MX-fp4 second weight term of the fp16x2 mode emulated in float64 (`mx4` = the format
+    `pack_mx4_lo` writes and the kernel builds for A).  By itself the term costs ~1e-4 per GEMM on the hidden states — an order
+    below one fp16 term's 5e-4 per weight — and under the mode's own activation roundings it stays inside the tolerance."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fp16_error_budget.py"), "mx", "tiny_hubert_pl"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rows = [l for l in out.stdout.splitlines() if l.startswith("| `tiny_hubert_pl`")]
+    assert len(rows) == 2
+    alone = [float(c) for c in rows[0].strip().strip("|").split("|")[2:]]
+    mode = [float(c) for c in rows[1].strip().strip("|").split("|")[2:]]
+    assert alone[0] == 0 and all(1e-6 < e < 3e-4 for e in alone[1:]), alone       # conv1, q|k|v, fc1, fc2, three, all four
+    assert all(e < 1e-3 for e in mode) and max(mode) < mode[0] + 1.5e-4, mode     # column 0: two fp16 terms
+
+
+def test_mx4_quantiser_of_the_emulation_is_the_documented_format():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import fp16_error_budget as FB
+
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((7, 96)) * np.repeat(np.array([1e-3, 1.0, 300.0]), 32)
+    q = FB.mx4(x)
+    for b in range(3):
+        blk, qb = x[:, 32 * b:32 * b + 32], q[:, 32 * b:32 * b + 32]
+        s = np.exp2(np.ceil(np.log2(np.abs(blk).max(-1, keepdims=True) / 6.0)))
+        codes = np.abs(qb) / s
+        assert np.isin(np.round(codes * 2) / 2, FB.E2M1).all() and (codes <= 6.0).all()
+        assert (np.sign(qb) * np.sign(blk) >= 0).all()
+        grid = np.concatenate([-FB.E2M1[::-1], FB.E2M1])
+        nearest = np.abs(blk[..., None] - grid * s[..., None]).min(-1)
+        assert (np.abs(qb - blk) <= nearest + 1e-15).all()
+    assert (FB.mx4(np.zeros((2, 32))) == 0).all()

@@ -24,6 +24,37 @@ def r16(x):
     return x.astype(np.float16).astype(np.float64)
 
 
+# ---- MX-fp4 emulation (round 5: the second weight term of S3ENC_F16X2 on the scaled-MFMA pipe, gemm16.hip MXW) -------------------
+E2M1 = np.array([0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0])
+
+
+def mx4(x):
+    """x (..., K) -> its MX-fp4 image, dequantised: per 32 elements along K an E8M0 scale 2^e (the tightest with max / 2^e <= 6) and
+    e2m1 values rounded to nearest (ties to the even code) — what `pack_mx4_lo` writes for W_lo and the kernel builds for A."""
+    K = x.shape[-1]
+    b = x.reshape(x.shape[:-1] + (K // 32, 32))
+    amax = np.abs(b).max(-1, keepdims=True)
+    with np.errstate(divide="ignore"):
+        e = np.where(amax > 0, np.ceil(np.log2(np.maximum(amax, 1e-300) / 6.0)), -127.0)
+    e = np.maximum(e, -127.0)
+    s = np.exp2(e)
+    a = np.abs(b) / s
+    idx = np.clip(np.searchsorted(E2M1, a, side="left"), 1, 7)          # E2M1[idx - 1] < a <= E2M1[idx] (a > 0)
+    lo_v, hi_v = E2M1[idx - 1], E2M1[idx]
+    up = (a - lo_v > hi_v - a) | ((a - lo_v == hi_v - a) & (idx % 2 == 0))  # ties: the even code
+    q = np.where(a <= 0, 0.0, np.where(up, hi_v, lo_v))
+    return (np.sign(b) * q * s).reshape(x.shape)
+
+
+def mm(site, rounded, a, Wm):
+    """a @ Wm.T as the fp16x2 GEMM `site` computes it: exact weights (two fp16 terms) — or, with "mx_<site>" in `rounded`,
+    a @ fp16(W).T + mx4(a) @ mx4(W - fp16(W)).T (the lo term as MX-fp4 images of both operands)."""
+    if "mx_" + site not in rounded:
+        return a @ Wm.T
+    w_hi = r16(Wm)
+    return a @ w_hi.T + mx4(a) @ mx4(Wm - w_hi).T
+
+
 def run(cfg, W, wavs, rounded):
     rd = lambda site, x: r16(x) if site in rounded else x
     dt = np.float64
@@ -40,7 +71,7 @@ def run(cfg, W, wavs, rounded):
     # "conv" = the outputs of conv0 .. conv(n-2) (the last conv feeds the fp32 LayerNorm / is rounded under "feat");
     # "conv<=i" = only the outputs of conv0 .. conv i
     upto = len(cfg.conv_layers) - 2 if "conv" in rounded else max([int(s[6:]) for s in rounded if s.startswith("conv<=")], default=-1)
-    feats = feature_extractor_rounded(cfg, W, padded, upto) if upto >= 0 else O.feature_extractor(cfg, W, padded, None)
+    feats = feature_extractor_rounded(cfg, W, padded, upto, "mx_conv1" in rounded) if (upto >= 0 or "mx_conv1" in rounded) else O.feature_extractor(cfg, W, padded, None)
     T = feats.shape[1]
     valid = [cfg.valid_frames(n, n_max) for n in lens]
     x = feats
@@ -68,9 +99,9 @@ def run(cfg, W, wavs, rounded):
         def attn(a):
             a_exact = a
             a = rd("ln_out", a)
-            q = (a @ W[f"{p}.self_attn.q_proj.weight"].T + W[f"{p}.self_attn.q_proj.bias"]) * dh ** -0.5
-            k = a @ W[f"{p}.self_attn.k_proj.weight"].T + W[f"{p}.self_attn.k_proj.bias"]
-            v = a @ W[f"{p}.self_attn.v_proj.weight"].T + W[f"{p}.self_attn.v_proj.bias"]
+            q = (mm("qkv", rounded, a, W[f"{p}.self_attn.q_proj.weight"]) + W[f"{p}.self_attn.q_proj.bias"]) * dh ** -0.5
+            k = mm("qkv", rounded, a, W[f"{p}.self_attn.k_proj.weight"]) + W[f"{p}.self_attn.k_proj.bias"]
+            v = mm("qkv", rounded, a, W[f"{p}.self_attn.v_proj.weight"]) + W[f"{p}.self_attn.v_proj.bias"]
             sp = lambda t: t.reshape(B, T, H, dh).transpose(0, 2, 1, 3)
             q, k, v = sp(rd("q", q)), sp(rd("k", k)), sp(rd("v", v))
             s = q @ k.transpose(0, 1, 3, 2)
@@ -93,8 +124,8 @@ def run(cfg, W, wavs, rounded):
             return rd("attn_out", o) @ W[f"{p}.self_attn.out_proj.weight"].T + W[f"{p}.self_attn.out_proj.bias"]
 
         def ffn(a):
-            h = O.gelu(rd("ln_out", a) @ W[f"{p}.fc1.weight"].T + W[f"{p}.fc1.bias"])
-            return rd("fc1_out", h) @ W[f"{p}.fc2.weight"].T + W[f"{p}.fc2.bias"]
+            h = O.gelu(mm("fc1", rounded, rd("ln_out", a), W[f"{p}.fc1.weight"]) + W[f"{p}.fc1.bias"])
+            return mm("fc2", rounded, rd("fc1_out", h), W[f"{p}.fc2.weight"]) + W[f"{p}.fc2.bias"]
 
         if cfg.layer_norm_first:
             x = x + attn(O.layer_norm(x, *ln1))
@@ -108,24 +139,63 @@ def run(cfg, W, wavs, rounded):
     return hidden
 
 
-def feature_extractor_rounded(cfg, W, padded, upto):
-    """oracle feature_extractor with the OUTPUT of conv layers 0 .. upto rounded to fp16 (the next conv GEMM's operand)."""
+def feature_extractor_rounded(cfg, W, padded, upto, mx_conv1=False):
+    """oracle feature_extractor with the OUTPUT of conv layers 0 .. upto rounded to fp16 (the next conv GEMM's operand); mx_conv1:
+    conv1's lo weight term as MX-fp4 images (k axis tap-major, j * Cin + ci: a 32-block is 32 consecutive channels of one tap)."""
     taps = {}
-    orig = O.gelu
-    calls = [0]
+    orig, orig_conv = O.gelu, O.conv1d_channel_last
+    calls, convs = [0], [0]
 
     def gelu_r(x):
         calls[0] += 1
         return r16(orig(x)) if calls[0] - 1 <= upto else orig(x)
 
-    O.gelu = gelu_r
+    def conv_mx(x, w, bias, stride):
+        convs[0] += 1
+        if not (mx_conv1 and convs[0] == 2):
+            return orig_conv(x, w, bias, stride)
+        B, L, Cin = x.shape
+        Cout, _, k = w.shape
+        Lout = (L - k) // stride + 1
+        x = np.ascontiguousarray(x)
+        it = x.itemsize
+        win = np.lib.stride_tricks.as_strided(x, shape=(B, Lout, k * Cin), strides=(L * Cin * it, stride * Cin * it, it)).reshape(B * Lout, k * Cin)
+        wm = np.ascontiguousarray(w.transpose(0, 2, 1).reshape(Cout, k * Cin))  # [co, j*Cin+ci]
+        w_hi = r16(wm)
+        y = win @ w_hi.T + mx4(np.ascontiguousarray(win)) @ mx4(wm - w_hi).T
+        y = y.reshape(B, Lout, Cout)
+        return y + bias if bias is not None else y
+
+    O.gelu, O.conv1d_channel_last = gelu_r, conv_mx
     try:
         return O.feature_extractor(cfg, W, padded, taps)
     finally:
-        O.gelu = orig
+        O.gelu, O.conv1d_channel_last = orig, orig_conv
+
+
+def main_mx(names):
+    """`fp16_error_budget.py mx [fixtures]`: the fp16x2 mode's error with the MX second term on each GEMM (the CPU twin of
+    tools/mx_mask_sweep.py's GPU table; float64 sums, the mode's activation-rounding sites as the engine has them)."""
+    masks = [((), "two fp16 terms"), (("mx_conv1",), "conv1"), (("mx_qkv",), "q|k|v"), (("mx_fc1",), "fc1"), (("mx_fc2",), "fc2"),
+             (("mx_qkv", "mx_fc1", "mx_fc2"), "q|k|v + fc1 + fc2"), (("mx_conv1", "mx_qkv", "mx_fc1", "mx_fc2"), "all four")]
+    print("| fixture | activation sites rounded | " + " | ".join(d for _, d in masks) + " |")
+    print("|---|---|" + "---:|" * len(masks))
+    for name in names:
+        meta, cfg, weights, wavs, golden, _ = load_golden(name)
+        W = {k: v.astype(np.float64) for k, v in weights.items()}
+        exact = run(cfg, W, wavs, set())
+        err = lambda hs: max(O.rel_err(h, e) for h, e in zip(hs, exact))
+        # what S3ENC_F16X2 rounds today: conv0's output (conv1's operand), the LayerNorm outputs, q / k / v / P, GELU(fc1)
+        act = {"conv<=0", "ln_out", "q", "k", "v", "p", "fc1_out"}
+        for label, base in (("none (the MX term alone)", set()), ("the mode's", act)):
+            cells = ["%.2e" % err(run(cfg, W, wavs, base | set(m))) if (m or base) else "0" for m, _ in masks]
+            print(f"| `{name}` | {label} | " + " | ".join(cells) + " |")
+            sys.stdout.flush()
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "mx":
+        return main_mx(sys.argv[2:] or ["wav2vec2_base_pl", "hubert_base_pl"])
     names = sys.argv[1:] or ["wav2vec2_base_pl", "hubert_base_pl", "hubert_base_pseudo"]
     for name in names:
         meta, cfg, weights, wavs, golden, _ = load_golden(name)
