@@ -202,9 +202,9 @@ int s3enc_create(const s3enc_config* cfg, const s3enc_tensor* tensors, int32_t n
     // (round 5: layer-norm extractors too — their conv outputs are LayerNorm'd + GELU'd, which renormalises the scale but not the
     // relative rounding noise: six stacked fp16 roundings are 6.0e-4 on HuBERT-large and, amplified by the bias-sharpened
     // attention of WavLM-large, 1.07e-3 alone on pretrained-like statistics — tools/fp16_error_budget.py, profiles/r05_fp16_cliff.md)
-    if (e->x2 && !c.no_feature_layer_norm && c.n_conv >= 3 && C >= 128 && !(C & 31)) {
-        bool ok = true;  // every conv from the second on must be a shape the three-term GEMM takes (gemm_x3_eligible)
-        for (int i = 2; i < c.n_conv; ++i) ok = ok && !(((long)c.conv_kernel[i] * C) & 31) && !(((long)c.conv_stride[i] * C * 4) & 15);
+    if (e->x2 && !c.no_feature_layer_norm && c.n_conv >= 3) {
+        bool ok = true;  // every conv from the second on must be a shape the three-term GEMM takes
+        for (int i = 2; i < c.n_conv; ++i) ok = ok && x3_shape_ok(C, (long)c.conv_kernel[i] * C, (long)c.conv_stride[i] * C);
         if (ok) e->x2_conv_f32_from = 2;
     }
     e->conv.resize(c.n_conv);
@@ -252,7 +252,7 @@ int s3enc_create(const s3enc_config* cfg, const s3enc_tensor* tensors, int32_t n
     }
     GET("post_extract_proj.weight", (long)D * C, t);
     UP(upload_gemm_w(e->proj_w, t, D, C, e->dtype, e->x2));
-    e->x2_proj_f32 = e->x2 && !c.no_feature_layer_norm && c.family != S3ENC_DISTILLER && D >= 128 && !(C & 31) && !(D & 3);
+    e->x2_proj_f32 = e->x2 && !c.no_feature_layer_norm && c.family != S3ENC_DISTILLER && x3_shape_ok(D, C, C);
     if (e->x3 || e->x2_proj_f32) UP(upload_x3(e->proj_w3, t, D, C));
     GET("post_extract_proj.bias", D, t);
     UP(upload_f32(e->proj_b, t));
@@ -330,7 +330,7 @@ int s3enc_create(const s3enc_config* cfg, const s3enc_tensor* tensors, int32_t n
     // (attention.hip: softmax as exp2 with no per-score multiply), so those handles fold log2(e) in as well — one rounding
     // of the weight to the operand type either way.  The exact-fp32 and split-precision handles keep the power-of-two scale.
     const float qscale = (1.0f / std::sqrt((float)(D / H))) * (e->dtype != F32 ? 1.44269504088896340736f : 1.0f);
-    e->x2_attn_f32 = e->x2 && !multires && D >= 128 && !(D & 31);  // (gemm_x3_eligible for N = K = D; the U-net keeps 16-bit)
+    e->x2_attn_f32 = e->x2 && !multires && x3_shape_ok(D, D, D);  // (the U-net keeps 16-bit)
     // one TransformerSentenceEncoderLayer named `p` (…layers.N); returns non-zero after fail() (e is already deleted)
     auto load_layer = [&](const std::string& p, LayerW& L) -> int {
         std::vector<float> w(3L * D * D), bb(3L * D);

@@ -476,6 +476,26 @@ struct Prof {
     }
 };
 
+// S3ENC_F16X2 hybrids: would the three-term GEMM take an (N, K) product whose A rows are `lda` fp32 elements apart?  The REAL
+// predicate (gemm_x3_eligible) on a representative call — 256-byte aligned operands as the workspace allocator hands them out, a
+// dense fp32 output — instead of a hand-copied subset of it: s3enc_create decides the hybrids with this, so the forward's
+// "not a shape of the three-term GEMM" failures cannot be reached through a drift between two predicates (round-4 ADVICE).
+inline bool x3_shape_ok(long N, long K, long lda) {
+    GemmParams g{};
+    g.A = (const void*)(uintptr_t)256;
+    g.W_x3 = (const void*)(uintptr_t)256;
+    g.out32 = (float*)(uintptr_t)256;
+    g.lda = lda;
+    g.a_bs = 4 * lda;  // any multiple of lda: the extractor's batch stride is L * C, the encoder's GEMMs are one batch
+    g.M = 256;
+    g.N = (int)N;
+    g.K = (int)K;
+    g.batches = 1;
+    g.ldo = N;
+    g.o_bs = 256 * N;
+    return gemm_x3_eligible(g);
+}
+
 // S3ENC_F16X2: every GEMM of the handle runs on its [hi | lo] weight rows — with the lo term as an MX-fp4 image where one was
 // packed for exactly this weight (round 5: gemm16.hip MXW; launch_gemm falls back to the two-term loop for other shapes)
 inline GemmParams wsplit_of(const s3enc_encoder* e, GemmParams g) {

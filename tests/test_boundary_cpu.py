@@ -189,3 +189,37 @@ def test_mx_second_term_tuning_key_is_a_bit_mask():
         _lib.check(lib.s3enc_set_tuning(b"gemm16_mx", mask))
     assert lib.s3enc_set_tuning(b"gemm16_mx", 32) != 0
     _lib.check(lib.s3enc_set_tuning(b"gemm16_mx", 14))
+
+
+def test_fp16x2_hybrids_are_decided_by_the_real_three_term_predicate(tmp_path):
+    """s3enc_create switches the fp16x2 hybrids on (conv2.. / post_extract_proj / out_proj on fp32 activations through the
+    three-term GEMM) iff `x3_shape_ok` — gemm_x3_eligible itself on a representative call — says the kernel takes the shape: the
+    path's shapes must all pass (else the mode silently loses its parity margin), degenerate ones must not (else the forward fails)."""
+    import os
+    import shutil
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    exe = str(tmp_path / "x3_shape_harness")
+    lib_dir = os.path.join(root, "s3prl_amd")
+    build = subprocess.run([hipcc, "-O1", "-std=c++17", "--offload-arch=gfx950", "-I", os.path.join(lib_dir, "csrc"), "-I", os.path.join(root, "include"),
+                            os.path.join(root, "tests", "native", "x3_shape_harness.hip"), "-L", lib_dir, "-ls3enc", f"-Wl,-rpath,{lib_dir}", "-o", exe],
+                           capture_output=True, text=True, timeout=600)
+    assert build.returncode == 0, build.stderr[-2000:]
+    cases = [  # (N, K, lda) -> expected
+        ((512, 1536, 1024), 1), ((512, 1024, 1024), 1),          # conv2-4 (k = 3, s = 2), conv5-6 (k = 2, s = 2) at C = 512
+        ((768, 512, 512), 1), ((1024, 512, 512), 1),            # post_extract_proj base / large
+        ((768, 768, 768), 1), ((1024, 1024, 1024), 1),          # out_proj base / large
+        ((64, 128, 128), 0),                                    # N < 128: the tiny test models keep the 16-bit path
+        ((512, 1520, 1024), 0),                                 # K not a multiple of 32
+        ((512, 1536, 1022), 0),                                 # A rows not 16-byte granular
+        ((510, 1536, 1024), 0),                                 # N not a multiple of 4
+    ]
+    args = [str(v) for shape, _ in cases for v in shape]
+    out = subprocess.run([exe] + args, capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr
+    got = [int(x) for x in out.stdout.split()]
+    assert got == [e for _, e in cases], list(zip(cases, got))
