@@ -121,3 +121,48 @@ def test_fairseq_layout_conversion(tmp_path):
     expert = amd.hubert_custom(str(src), fairseq=True)
     assert (tmp_path / "fairseq_style.converted.pt").is_file()
     assert expert.cfg.to_dict() == cfg.to_dict()
+
+
+def test_fairseq_layout_conversion_of_an_omegaconf_container(tmp_path, monkeypatch):
+    """Released fairseq checkpoints pickle ``cfg`` as an ``omegaconf.DictConfig`` (hubert/convert.py:22-40 reads it through
+    fairseq).  ``omegaconf`` is not installed here, so a stand-in package with the two things the branch touches — a picklable
+    container class and ``OmegaConf.to_container`` — exercises it: the converted checkpoint must equal the plain-dict one."""
+    import sys
+
+    import torch
+
+    pkg = tmp_path / "fake_site" / "omegaconf"
+    pkg.mkdir(parents=True)
+    (pkg / "__init__.py").write_text(
+        "class DictConfig:\n"
+        "    def __init__(self, content):\n"
+        "        self._content = {k: DictConfig(v) if isinstance(v, dict) else v for k, v in content.items()}\n"
+        "    def __getitem__(self, k):\n"
+        "        return self._content[k]\n"
+        "class OmegaConf:\n"
+        "    @staticmethod\n"
+        "    def to_container(cfg):\n"
+        "        return {k: OmegaConf.to_container(v) if isinstance(v, DictConfig) else v for k, v in cfg._content.items()}\n")
+    monkeypatch.syspath_prepend(str(tmp_path / "fake_site"))
+    sys.modules.pop("omegaconf", None)
+    import omegaconf
+
+    import s3prl_amd.hub as amd
+    from s3prl_amd.synth import named_config, synth_weights
+
+    try:
+        cfg = named_config("tiny_hubert")
+        sd = {k: torch.from_numpy(v) for k, v in synth_weights(cfg, 3).items()}
+        model_cfg = dict(extractor_mode="default", encoder_layers=3, encoder_embed_dim=128, encoder_ffn_embed_dim=256,
+                         encoder_attention_heads=2, conv_pos=16, conv_pos_groups=4, activation_fn="gelu",
+                         conv_feature_layers=str([tuple(t) for t in cfg.conv_layers]))
+        src = tmp_path / "fairseq_omegaconf.pt"
+        torch.save({"cfg": omegaconf.DictConfig({"task": {"normalize": False, "label_rate": 50.0}, "model": model_cfg}), "model": sd,
+                    "task_state": {"dictionaries": [["a", "b"]]}}, str(src))
+        expert = amd.hubert_custom(str(src), fairseq=True)
+        assert expert.cfg.to_dict() == cfg.to_dict()
+        conv = torch.load(str(tmp_path / "fairseq_omegaconf.converted.pt"), map_location="cpu", weights_only=False)
+        assert isinstance(conv["model_cfg"], dict) and conv["model_cfg"]["encoder_layers"] == 3
+        assert conv["task_cfg"] == {"normalize": False, "label_rate": 50.0} and conv["dictionaries_symbols"] == [["a", "b"]]
+    finally:
+        sys.modules.pop("omegaconf", None)
