@@ -262,7 +262,8 @@ int s3enc_debug_occupy_cus(int32_t workgroups, int32_t threads, double milliseco
  *                   measured within 1-3 % of the default (profiles/r05_gemm16_loop_probe.md);
  *   "gemm16_mx":    S3ENC_F16X2 only, bit mask: which GEMMs take their second weight term as an MX-fp4 image on the scaled-MFMA pipe
  *                   (gemm16.hip MXW: 4.8e-5 of weight error per GEMM instead of 5e-7) where the shape allows — 1 conv1, 2 q|k|v, 4 fc1,
- *                   8 fc2, 16 = also shapes whose 256-row tiling needs fewer CU-rounds; default 14; 0 = two fp16 terms everywhere.  Results
+ *                   8 fc2, 16 = (read at s3enc_create) also weights whose 256-row tiling needs fewer CU-rounds at the reference batch — which weights
+ *                   take it is decided per weight, never per batch; default 14; 0 = two fp16 terms everywhere.  Results
  *                   differ at the 1e-5 ... 1e-4 level (profiles/r05_mx_second_term.md);
  *   "reserve_cus":  CUs the persistent one-workgroup-per-CU GEMM of the 16-bit modes leaves out of its grid (default 0; a measurement
  *                   knob — leaving CUs to a collective's channel kernels costs more than sharing them: profiles/r05_cu_contention.md);

@@ -839,16 +839,21 @@ bool gemm16_big_eligible(int dtype, const GemmParams& p) {
 }
 
 bool gemm16_mx_eligible(int dtype, const GemmParams& p) {
-    if (!(dtype == F16 && p.W4 && p.W4s && !(p.K & 127) && !((uintptr_t)p.W4 & 15) && !((uintptr_t)p.W4s & 3) && gemm16_big_eligible(dtype, p) &&
-          tuning().gemm16_mx != 0 && tuning().gemm16_big != 0))
-        return false;
-    // the MX K step exists for the 192-row tile only (its A-image registers fit beside 96 accumulators, not beside 128): shapes
-    // whose 256-row tiling needs fewer CU-rounds x rows keep the two-term loop (HuBERT-large fc2: one round of 252 tiles against
-    // two of 336 — measured 306 vs 237 us, profiles/r05_mx_second_term.md)
-    const long nt = (p.N + 255) / 256;
-    const long t256 = ((p.M + 255) / 256) * nt * p.batches, t192 = ((p.M + 191) / 192) * nt * p.batches;
+    return dtype == F16 && p.W4 && p.W4s && !(p.K & 127) && !((uintptr_t)p.W4 & 15) && !((uintptr_t)p.W4s & 3) && gemm16_big_eligible(dtype, p) &&
+           tuning().gemm16_mx != 0 && tuning().gemm16_big != 0;
+}
+
+// Which WEIGHTS get an MX image at all (s3enc_create).  The MX K step exists for the 192-row tile only (its A-image registers fit
+// beside 96 accumulators, not beside 128), and a shape whose 256-row tiling needs fewer CU-rounds x rows is faster on the two-term
+// loop (HuBERT-large fc2: ONE round of 252 tiles against two of 336 — 306 vs 237 us, profiles/r05_mx_second_term.md).  The rule is
+// evaluated per weight at the path's reference batch (32 x 10 s: M = 15968 rows), NOT per call: which kernel multiplies a row must
+// not depend on the batch the row sits in — one utterance alone, a data-parallel shard and the full batch give the same bits.
+bool gemm16_mx_weight_rule(long N, long K) {
+    if ((K & 127) || N < 128) return false;
+    const long M = 15968, nt = (N + 255) / 256;
+    const long t256 = ((M + 255) / 256) * nt, t192 = ((M + 191) / 192) * nt;
     const long c256 = ((t256 + 255) / 256) * 256, c192 = ((t192 + 255) / 256) * 192;
-    return c192 <= c256 || (tuning().gemm16_mx & 16);  // (bit 4: force, measurements)
+    return c192 <= c256;
 }
 
 hipError_t launch_gemm16_big(int dtype, const GemmParams& p, hipStream_t stream) {

@@ -37,7 +37,7 @@ struct Tuning {
                            // within +-1-3 % of 0: profiles/r05_gemm16_loop_probe.md — opt-in)
     int gemm16_mx = 14;    // S3ENC_F16X2, bit mask: which GEMMs take their second weight term as an MX-fp4 image on the scaled-MFMA pipe
                            // where the shape allows (gemm16.hip MXW) — 1 conv1, 2 q|k|v, 4 fc1, 8 fc2; 0 = two fp16 terms everywhere;
-                           // 16 = also shapes whose 256-row tiling is cheaper (measurements).  Default 14: conv1 stays on two fp16 terms —
+                           // 16 = (read at s3enc_create) also the weights whose 256-row tiling is cheaper at the reference batch (measurements).  Default 14: conv1 stays on two fp16 terms —
                            // its A operand (conv0's GroupNorm'd output with loud channels) is the one block-scaled fp4 images suit least
                            // (wav2vec2_base_pl 6.0e-4 with 14, 7.9e-4 with 15: profiles/r05_mx_second_term.md)
     int reserve_cus = 0;   // gemm16.hip, persistent loop: CUs left out of the one-workgroup-per-CU grid.  Measured (profiles/r05_cu_contention.md):
@@ -103,6 +103,7 @@ struct GemmParams {
     int mxw = 0;
 };
 bool gemm16_mx_eligible(int dtype, const GemmParams& p);
+bool gemm16_mx_weight_rule(long N, long K);  // which weights get an MX image at s3enc_create (per weight, batch-independent)
 // gemm_x3.hip: fp32-class GEMM from three bf16 MFMAs per product (opt-in compute mode S3ENC_F32X3)
 bool gemm_x3_eligible(const GemmParams& p);
 hipError_t launch_gemm_x3(const GemmParams& p, hipStream_t stream);

@@ -223,3 +223,38 @@ def test_fp16x2_hybrids_are_decided_by_the_real_three_term_predicate(tmp_path):
     assert out.returncode == 0, out.stderr
     got = [int(x) for x in out.stdout.split()]
     assert got == [e for _, e in cases], list(zip(cases, got))
+
+
+def test_mx_second_term_weight_rule_is_per_weight_not_per_batch(tmp_path):
+    """gemm16_mx_weight_rule (gemm16.hip): the MX K step exists for the 192-row tile only, so a weight whose 256-row tiling needs
+    fewer CU-rounds x rows at the path's reference batch (M = 15968) keeps two fp16 terms — HuBERT-base q|k|v, fc1, fc2 take the MX
+    image, HuBERT-large q|k|v does, its fc1 / fc2 do not (306 vs 237 us when forced: profiles/r05_mx_second_term.md).  The decision
+    is made per WEIGHT at s3enc_create, never per call: gemm16_mx_eligible (the per-call check) must say the same for one utterance
+    (M = 99), a shard (M = 1996) and the full batch, or a row's bits would depend on the batch it sits in."""
+    import os
+    import shutil
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    exe = str(tmp_path / "mx_rule_harness")
+    lib_dir = os.path.join(root, "s3prl_amd")
+    build = subprocess.run([hipcc, "-O1", "-std=c++17", "--offload-arch=gfx950", "-I", os.path.join(lib_dir, "csrc"), "-I", os.path.join(root, "include"),
+                            os.path.join(root, "tests", "native", "mx_rule_harness.hip"), "-L", lib_dir, "-ls3enc", f"-Wl,-rpath,{lib_dir}", "-o", exe],
+                           capture_output=True, text=True, timeout=600)
+    assert build.returncode == 0, build.stderr[-2000:]
+    weights = {(2304, 768): 1, (3072, 768): 1, (768, 3072): 1,          # HuBERT-base q|k|v, fc1, fc2
+               (3072, 1024): 1, (4096, 1024): 0, (1024, 4096): 0,       # HuBERT-large / WavLM-large q|k|v, fc1, fc2
+               (2304, 704): 0, (64, 768): 0}                            # K % 128 != 0; N < 128
+    batches = (99, 1996, 15968, 23968)
+    cases = [(M, N, K) for (N, K) in weights for M in batches]
+    out = subprocess.run([exe] + [str(v) for c in cases for v in c], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr
+    rows = [tuple(int(x) for x in l.split()) for l in out.stdout.strip().splitlines()]
+    assert len(rows) == len(cases)
+    for (M, N, K), (rule, eligible) in zip(cases, rows):
+        assert rule == weights[(N, K)], (M, N, K, rule)
+        # the per-call check depends on the weight's shape and alignment only — never on M
+        assert eligible == (1 if (K % 128 == 0 and N >= 128) else 0), (M, N, K, eligible)
