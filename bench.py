@@ -53,7 +53,7 @@ MODEL_NAMES = {"hubert_base": "HuBERT-base", "hubert_large": "HuBERT-large", "wa
                "wav2vec2_large": "wav2vec2-large", "wavlm_base_plus": "WavLM-base+", "wavlm_large": "WavLM-large",
                "wavlm_base": "WavLM-base", "distilhubert": "DistilHuBERT"}
 DTYPE_NAMES = {"fp32": "f32", "bf16": "bf16", "fp16": "f16", "fp32x3": "bf16x3 (split fp32, fp32 accumulate)",
-               "fp16x2": "f16x2 (fp16 activations x two-term fp16 weights, fp32 accumulate)"}
+               "fp16x2": "f16x2 (fp16 activations x two-term weights: fp16 + fp16, or fp16 + MX-fp4 on the scaled-MFMA pipe for q|k|v / fc1 / fc2; fp32 accumulate)"}
 # default timed region >= 5 s of GPU work at the default workload (HuBERT-base 32 x 10 s): steps per dtype
 DEFAULT_STEPS = {"fp32": 150, "fp32x3": 330, "bf16": 700, "fp16": 700, "fp16x2": 500}
 
