@@ -290,9 +290,9 @@ def main():
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
 
-    if args.tune:
-        from s3prl_amd import _lib
+    from s3prl_amd import _lib
 
+    if args.tune:
         for kv in args.tune:
             k, v = kv.split("=")
             _lib.check(_lib.load().s3enc_set_tuning(k.encode(), int(v)), "s3enc_set_tuning")
@@ -372,12 +372,19 @@ def main():
             steal["stream"] = torch.cuda.Stream(device=dev)
         _lib.check(_lib.load().s3enc_debug_occupy_cus(args.steal_cus, 256, steal["ms"], steal["stream"].cuda_stream), "s3enc_debug_occupy_cus")
 
+    # average shader clock of a timed region (s3enc_debug_clock_sample): `clock_ghz` in the JSON line, so that a slow box reads as a
+    # slow box and not as a regression (round 5: the driver's box ran every kernel 2.0-3.5 % slower than the builder's lease)
+    clock = {"buf": torch.zeros((2, 3), dtype=torch.int64, device=dev), "ghz": None}
+
     def timed(k, exchange=True, profile=False):
         """k steps bracketed by barrier + synchronize on both sides; max over ranks."""
         prof_steps = 0
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+        clk = clock["buf"]
+        if clk is not None:  # shader / reference counter pair on the compute stream, in front of the first step (ops.hip)
+            _lib.check(_lib.load().s3enc_debug_clock_sample(clk[0].data_ptr(), torch.cuda.current_stream(dev).cuda_stream))
         t0 = time.perf_counter()
         for i in range(k):
             on = profile and i % PROF_EVERY == 0
@@ -386,6 +393,9 @@ def main():
             prof_steps += int(on)
             occupy()
             step(exchange)
+        if clk is not None:  # ... and behind the last one: enqueued, not waited for — nothing is added to the timed region but two
+            # one-wave launches; read after the region's own synchronize
+            _lib.check(_lib.load().s3enc_debug_clock_sample(clk[1].data_ptr(), torch.cuda.current_stream(dev).cuda_stream))
         if steal["stream"] is not None:
             # the compute stream's last step is the end of the timed region; the idle workgroups queued past it are not work
             torch.cuda.current_stream(dev).synchronize()
@@ -394,6 +404,10 @@ def main():
         if world > 1:
             dist.barrier()
         el = time.perf_counter() - t0
+        if clk is not None:
+            a, b = clk[0].cpu().tolist(), clk[1].cpu().tolist()
+            if a[2] > 0 and b[2] == a[2] and b[1] > a[1]:  # [2] = the reference rate in kHz, written by the sampling workgroup
+                clock["ghz"] = (b[0] - a[0]) / (b[1] - a[1]) * a[2] * 1e-6
         if steal["stream"] is not None:
             el = el_steal
         if profile:
@@ -421,6 +435,7 @@ def main():
         # in extra, untimed steps after the timed region.
         PROF_EVERY = 4
         elapsed, prof_steps = timed(steps, True, not args.no_profile)
+        headline_clock = clock["ghz"]
         prof = enc.profile_read()
         comm = None
         if world > 1:  # always reported for N > 1: what the exchange moves and how much of it the compute does not hide
@@ -477,6 +492,9 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3),
             "timed_region_s": round(elapsed, 2),
+            # average shader clock over the timed region: d(s_memtime) / d(s_memrealtime) x 100 MHz between two one-wave samples on
+            # the compute stream (the part clocks to its power budget: 2.4 GHz nominal, ~2.1-2.2 under the fp32 MFMA stream)
+            "clock_ghz": round(headline_clock, 3) if headline_clock else None,
             "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None,
@@ -582,13 +600,19 @@ def main():
                     for _ in range(3):
                         enc2.forward(wavs, out=out2)
                     torch.cuda.synchronize()
+                    cs = torch.cuda.current_stream(dev).cuda_stream
+                    _lib.check(_lib.load().s3enc_debug_clock_sample(clock["buf"][0].data_ptr(), cs))
                     t1 = time.perf_counter()
                     for _ in range(20):
                         enc2.forward(wavs, out=out2)
+                    _lib.check(_lib.load().s3enc_debug_clock_sample(clock["buf"][1].data_ptr(), cs))
                     torch.cuda.synchronize()
                     dt = (time.perf_counter() - t1) / 20
+                    ca, cb = clock["buf"][0].cpu().tolist(), clock["buf"][1].cpu().tolist()
+                    ghz = (cb[0] - ca[0]) / (cb[1] - ca[1]) * ca[2] * 1e-6 if ca[2] > 0 and cb[2] == ca[2] and cb[1] > ca[1] else None
                     err = max(O.rel_err(out2[l][:ns].cpu().numpy(), ref_t[l].numpy()) for l in range(NL + 1))
                     other[mode] = {"value": round(B * T / dt, 1), "ms_per_step": round(dt * 1e3, 3),
+                                   "clock_ghz": round(ghz, 3) if ghz else None,
                                    "max_layer_rel_err_vs_torch_oracle": float(f"{err:.3e}")}
                     enc2.close()
                 del out2

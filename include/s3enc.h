@@ -243,7 +243,11 @@ int s3enc_profile_read(s3enc_handle h, s3enc_profile_entry* entries, int32_t max
 int s3enc_debug_tap(s3enc_handle h, const char* name, float* host_out, int64_t max_elems, int64_t* n_elems);
 /* Measurement hook (no reference counterpart): `workgroups` x `threads` idle threads that hold their CU slots for `milliseconds` on
  * `stream` — a stand-in for a collective's channel kernels running beside the encoder (bench.py --steal-cus). */
-int s3enc_debug_occupy_cus(int32_t workgroups, int32_t threads, double milliseconds, void* stream);
+int s3enc_debug_occupy_cus(int32_t workgroups, int32_t threads, double milliseconds, void* stream);  /* milliseconds <= 10000 */
+/* Measurement hook (no reference counterpart): writes {shader-clock counter, reference-clock counter, reference rate in kHz} of XCD 0
+ * to three device uint64 on `stream`.  Two samples around a region give its average shader clock: d(out[0]) / d(out[1]) x out[2]
+ * (hipDeviceAttributeWallClockRate, 100 MHz) — bench.py's `clock_ghz`, so that a slow box reads as a slow box. */
+int s3enc_debug_clock_sample(uint64_t* out3_device, void* stream);
 
 /* Process-wide tuning knobs (kernel-variant selection for A/B measurements; results are unchanged, except "gelu32"):
  *   "gemm_variant": gemm.hip's 128x128 kernel: bit 0 = 64-byte K stages (else 128), bit 1 = LDS-DMA staging, bit 2 = no
@@ -265,6 +269,10 @@ int s3enc_debug_occupy_cus(int32_t workgroups, int32_t threads, double milliseco
  *                   8 fc2, 16 = (read at s3enc_create) also weights whose 256-row tiling needs fewer CU-rounds at the reference batch — which weights
  *                   take it is decided per weight, never per batch; default 14; 0 = two fp16 terms everywhere.  Results
  *                   differ at the 1e-5 ... 1e-4 level (profiles/r05_mx_second_term.md);
+ *                   The mask is read at s3enc_create: only the kinds it names get an image (narrowing it on a live handle works,
+ *                   widening needs a new handle);
+ *   "comm_self_p2p": S3ENC_EXCHANGE_DIRECT test hook: 1 = a rank's own block travels as an ncclSend-to-self / ncclRecv-from-self pair
+ *                   inside the state's group instead of a device copy (how the all-pairs code executes on a one-GPU box); default 0;
  *   "reserve_cus":  CUs the persistent one-workgroup-per-CU GEMM of the 16-bit modes leaves out of its grid (default 0; a measurement
  *                   knob — leaving CUs to a collective's channel kernels costs more than sharing them: profiles/r05_cu_contention.md);
  *   "conv0_nt":     1 (default) = the fp32 conv0 kernel writes its activation with non-temporal stores, 0 = plain stores;

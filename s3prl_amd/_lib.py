@@ -93,6 +93,7 @@ _PROTOS = {
     "s3enc_op_gemm": (C.c_int, [_I32, _VP, _I64, _I64, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _VP, _VP, _VP, _VP,
                                 _I64, _I64, _VP]),
     "s3enc_debug_occupy_cus": (C.c_int, [_I32, _I32, C.c_double, _VP]),
+    "s3enc_debug_clock_sample": (C.c_int, [_VP, _VP]),
     "s3enc_op_layernorm": (C.c_int, [_I32, _VP, _VP, _VP, _I32, _I32, _I32, _VP, _VP, _VP]),
     "s3enc_op_attention": (C.c_int, [_I32, _VP, _VP, _VP, _I32, _I32, _I32, _VP, _I32, _VP, _VP]),
     "s3enc_op_conv0": (C.c_int, [_I32, C.POINTER(_VP), C.POINTER(_I64), _I32, _I64, _I32, _VP, _VP, _VP, _VP, _VP, _VP, _I32,

@@ -193,10 +193,13 @@ int s3enc_comm_exchange_states(s3enc_comm c, int32_t algo, const void* send, int
             continue;
         }
         char* own = dst + (size_t)c->rank * bytes_per_state;
-        if (own != src) HIP_TRY(hipMemcpyAsync(own, src, (size_t)bytes_per_state, hipMemcpyDeviceToDevice, c->stream));
-        if (c->world == 1) continue;
+        // the rank's own block: a device copy — or, under the tuning key comm_self_p2p, one more send / receive pair of the
+        // state's group with peer = rank (pstep 0), which is how the all-pairs code below runs on a one-GPU box
+        const bool self_p2p = s3::tuning().comm_self_p2p != 0 && own != src;
+        if (own != src && !self_p2p) HIP_TRY(hipMemcpyAsync(own, src, (size_t)bytes_per_state, hipMemcpyDeviceToDevice, c->stream));
+        if (c->world == 1 && !self_p2p) continue;
         RCCL_TRY(R.GroupStart());
-        for (int pstep = 1; pstep < c->world; ++pstep) {
+        for (int pstep = self_p2p ? 0 : 1; pstep < c->world; ++pstep) {
             const int to = (c->rank + pstep) % c->world, from = (c->rank - pstep + c->world) % c->world;
             ncclResult_t rs = R.Send(src, (size_t)bytes_per_state, ncclInt8, to, c->comm, c->stream);
             ncclResult_t rr = rs ? rs : R.Recv(dst + (size_t)from * bytes_per_state, (size_t)bytes_per_state, ncclInt8, from, c->comm, c->stream);

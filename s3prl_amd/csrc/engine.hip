@@ -186,11 +186,15 @@ int s3enc_create(const s3enc_config* cfg, const s3enc_tensor* tensors, int32_t n
     } while (0)
 
     // a GEMM weight in the handle's operand format; S3ENC_F16X2: + the MX-fp4 image of its lo term for the weights gemm16.hip's MXW K
-    // step pays for (gemm16_mx_weight_rule: decided per weight, never per batch; wsplit_of finds the image by the weight's pointer)
+    // step pays for (gemm16_mx_weight_rule: decided per weight, never per batch; wsplit_of finds the image by the weight's pointer).
+    // Only the kinds the tuning key gemm16_mx names AT CREATE TIME get an image (default 14: conv1's would never be read, and with
+    // gemm16_mx = 0 none would — seconds of host packing and the device bytes on a large model): the mask can be narrowed after
+    // s3enc_create, widening it needs a new handle.
 #define UPW(buf, vec, N_, K_, KIND)                                   \
     do {                                                              \
         UP(upload_gemm_w(buf, vec, N_, K_, e->dtype, e->x2));         \
-        if (e->x2 && (gemm16_mx_weight_rule(N_, K_) || ((tuning().gemm16_mx & 16) && !((K_) & 127) && (N_) >= 128))) { \
+        if (e->x2 && (tuning().gemm16_mx & ((KIND) | 16)) &&          \
+            (gemm16_mx_weight_rule(N_, K_) || ((tuning().gemm16_mx & 16) && !((K_) & 127) && (N_) >= 128))) { \
             std::unique_ptr<MxImage> img(new MxImage());              \
             UP(upload_mx4_lo(*img, vec, N_, K_));                     \
             img->kind = KIND;                                         \

@@ -246,9 +246,17 @@ inline void pack_mx4_lo(const std::vector<float>& w, long N, long K, std::vector
         pack_mx4_lo_rows(w.data(), K, 0, N, data.data(), scales.data());
         return;
     }
+    // thread creation can fail (pids cgroup, ulimit -u, bad_alloc) and nothing may throw across the C boundary: the row
+    // ranges whose thread did not start are packed on the calling thread, the started ones are always joined
     std::vector<std::thread> th;
-    for (unsigned t = 0; t < nt; ++t)
-        th.emplace_back(pack_mx4_lo_rows, w.data(), K, N * t / nt, N * (t + 1) / nt, data.data(), scales.data());
+    unsigned started = 0;
+    try {
+        th.reserve(nt);
+        for (; started < nt; ++started)
+            th.emplace_back(pack_mx4_lo_rows, w.data(), K, N * started / nt, N * (started + 1) / nt, data.data(), scales.data());
+    } catch (...) {
+    }
+    for (unsigned t = started; t < nt; ++t) pack_mx4_lo_rows(w.data(), K, N * t / nt, N * (t + 1) / nt, data.data(), scales.data());
     for (auto& x : th) x.join();
 }
 struct MxImage {

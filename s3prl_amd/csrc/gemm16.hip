@@ -846,13 +846,21 @@ bool gemm16_mx_eligible(int dtype, const GemmParams& p) {
 // Which WEIGHTS get an MX image at all (s3enc_create).  The MX K step exists for the 192-row tile only (its A-image registers fit
 // beside 96 accumulators, not beside 128), and a shape whose 256-row tiling needs fewer CU-rounds x rows is faster on the two-term
 // loop (HuBERT-large fc2: ONE round of 252 tiles against two of 336 — 306 vs 237 us, profiles/r05_mx_second_term.md).  The rule is
-// evaluated per weight at the path's reference batch (32 x 10 s: M = 15968 rows), NOT per call: which kernel multiplies a row must
+// evaluated per weight over the path's reference batches (below), NOT per call: which kernel multiplies a row must
 // not depend on the batch the row sits in — one utterance alone, a data-parallel shard and the full batch give the same bits.
+// Round 6: summed over three reference batches (8 / 32 / 64 utterances of 10 s: M = 3 992 / 15 968 / 31 936 rows) instead of the
+// bench's own 32 x 10 s alone — the decision is the same for every weight of the base and large models (base q|k|v, fc1, fc2,
+// conv1 and large q|k|v take the 192-row MX tile; large fc1 / fc2 do not), so no result bit moved; it is a property of the
+// weight's shape class, not of one benchmark batch.
 bool gemm16_mx_weight_rule(long N, long K) {
     if ((K & 127) || N < 128) return false;
-    const long M = 15968, nt = (N + 255) / 256;
-    const long t256 = ((M + 255) / 256) * nt, t192 = ((M + 191) / 192) * nt;
-    const long c256 = ((t256 + 255) / 256) * 256, c192 = ((t192 + 255) / 256) * 192;
+    const long nt = (N + 255) / 256;
+    long c256 = 0, c192 = 0;  // row-rounds of the 256-row two-term tile against the 192-row MX tile over 256 CUs
+    for (long M : {3992L, 15968L, 31936L}) {
+        const long t256 = ((M + 255) / 256) * nt, t192 = ((M + 191) / 192) * nt;
+        c256 += ((t256 + 255) / 256) * 256;
+        c192 += ((t192 + 255) / 256) * 192;
+    }
     return c192 <= c256;
 }
 

@@ -51,6 +51,10 @@ struct Tuning {
                            // working set per layer: fc2 -3.6 %, LayerNorm -4 % in the bf16 forward, round 4), 0 = two buffers
     int gelu32 = 1;        // S3ENC_F32: 1 = the one-transcendental GELU of every mode (common.h gelu_fast; fp32 rounding level), 0 = libm erff
     int x3_pack_cache = 0; // s3enc_op_gemm(S3ENC_F32X3): keep the packed image of the last weight (micro-benchmarks)
+    int comm_self_p2p = 0; // comm.hip, S3ENC_EXCHANGE_DIRECT: 1 = a rank's OWN block also travels as an ncclSend-to-self / ncclRecv-from-self
+                           // pair inside the state's group instead of a device copy — on a one-GPU box this is the only way the
+                           // all-pairs code (symbols, counts, datatype, group bracketing, stream order behind the layer events)
+                           // executes at all: RCCL refuses two ranks on one device.  A test hook; same bytes in the same places
 };
 extern Tuning g_tuning;
 extern thread_local const Tuning* t_tuning;  // the current handle's override, or null

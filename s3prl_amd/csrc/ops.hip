@@ -21,6 +21,7 @@ int tuning_set(Tuning& t, const char* key, int value, const char** err) {
         {"ws_inplace", &Tuning::ws_inplace, 0, 1},           {"gemm16_pp", &Tuning::gemm16_pp, 0, 3},
         {"gemm16_mx", &Tuning::gemm16_mx, 0, 31},            {"reserve_cus", &Tuning::reserve_cus, 0, 128},
         {"x3_pack_cache", &Tuning::x3_pack_cache, 0, 1},     {"gelu32", &Tuning::gelu32, 0, 1},
+        {"comm_self_p2p", &Tuning::comm_self_p2p, 0, 1},
     };
     static thread_local char msg[160];
     if (!key) {
@@ -153,11 +154,40 @@ __global__ void occupy_kernel(long long ticks) {
 }
 }  // namespace
 int s3enc_debug_occupy_cus(int32_t workgroups, int32_t threads, double milliseconds, void* stream) {
-    if (workgroups <= 0 || threads <= 0 || threads > 1024 || milliseconds < 0) return fail("s3enc_debug_occupy_cus: bad argument");
+    // (the hold is bounded: a typo in `milliseconds` must not be able to hang the GPU for an arbitrary time)
+    if (workgroups <= 0 || threads <= 0 || threads > 1024 || !(milliseconds >= 0) || milliseconds > 10000.0)
+        return fail("s3enc_debug_occupy_cus: bad argument (workgroups > 0, 0 < threads <= 1024, 0 <= milliseconds <= 10000)");
     int dev = 0, khz = 0;
     HIP_TRY(hipGetDevice(&dev));
     if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) khz = 100000;  // 100 MHz
     hipLaunchKernelGGL(occupy_kernel, dim3(workgroups), dim3(threads), 0, (hipStream_t)stream, (long long)(milliseconds * khz));
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// Measurement hook: the shader clock a timed region really ran at.  s_memtime ticks once per shader cycle, s_memrealtime at the
+// constant reference rate (hipDeviceAttributeWallClockRate, 100 MHz): two samples on the SAME stream around a region give its
+// average clock as d(shader) / d(reference) x rate — no concurrent probe, nothing perturbed.  Every XCD has its own counters, so the
+// sample is taken by a workgroup that finds itself on XCD 0 (64 workgroups go round-robin over the 8 XCDs; the first claims).
+namespace {
+__global__ void clock_sample_kernel(unsigned long long* out, unsigned long long ref_khz) {
+    if (threadIdx.x) return;
+    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;  // HW_REG_XCC_ID, bits 3:0
+    if (xcc != 0) return;
+    if (atomicCAS(&out[2], 0ull, ref_khz) != 0ull) return;
+    out[0] = __builtin_amdgcn_s_memtime();      // shader cycles
+    out[1] = __builtin_amdgcn_s_memrealtime();  // reference ticks
+    __threadfence_system();
+}
+}  // namespace
+int s3enc_debug_clock_sample(uint64_t* out3_device, void* stream) {
+    if (!out3_device) return fail("s3enc_debug_clock_sample: null argument");
+    int dev = 0, khz = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) khz = 100000;  // 100 MHz
+    HIP_TRY(hipMemsetAsync(out3_device, 0, 3 * sizeof(uint64_t), (hipStream_t)stream));
+    hipLaunchKernelGGL(clock_sample_kernel, dim3(64), dim3(64), 0, (hipStream_t)stream, (unsigned long long*)out3_device,
+                       (unsigned long long)khz);
     HIP_TRY(hipGetLastError());
     return 0;
 }

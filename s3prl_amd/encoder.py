@@ -54,6 +54,8 @@ class HipEncoder:
         self._h = h
         self.num_layers = cfg.encoder_layers
         self.embed_dim = cfg.encoder_embed_dim
+        self._forwards = 0   # forwards issued / the last one known to have been judged by check_finite (error messages name the range)
+        self._checked = 0
 
     def close(self):
         if getattr(self, "_h", None):
@@ -107,14 +109,25 @@ class HipEncoder:
         """Raise ``FloatingPointError`` if a forward since the last check produced a non-finite LayerNorm statistic — in the
         16-bit modes the sign of an fp16 / bf16 overflow on the way to the hidden states (an fp32 run only gets there from
         non-finite PCM).  ``wait=False`` never blocks: a forward still in flight is checked by the next call."""
+        issued = self._forwards
         st = self.status(wait)
+        settled = wait or not (st & _lib.STATUS_PENDING)   # every forward issued so far has reported
+        first = self._checked + 1
+        if settled:
+            self._checked = issued
         if st & _lib.STATUS_NONFINITE:
+            # the word accumulates over the forwards that finished since the last read: name the range, so that a deferred
+            # poll after forward N + k is not read as "forward N + k is bad" (its own output may be healthy)
+            which = (f"forward #{issued}" if first >= issued else f"one of the forwards #{first}..#{issued}") + \
+                    f" of this encoder ({'all of them have finished' if settled else 'the later ones are still running and are not judged yet'})"
             raise FloatingPointError(
-                f"libs3enc ({self.dtype}): a forward produced non-finite activations (a row LayerNorm met an inf / NaN "
+                f"libs3enc ({self.dtype}): {which} produced non-finite activations (a row LayerNorm met an inf / NaN "
                 "mean or variance) — its hidden states are not valid.  In fp16 / fp16x2 this is a range overflow "
-                "(|x| > 65504): use compute dtype fp32x3 / fp32 (or bf16) for this checkpoint; in fp32 check the waveforms")
+                "(|x| > 65504): use compute dtype fp32x3 / fp32 (or bf16) for this checkpoint; in fp32 check the waveforms.  "
+                "check='strict' raises on the forward that overflowed; a one-shot caller should call check_finite() after its forward")
 
     def _after_forward(self):
+        self._forwards += 1
         # strict: the caller pays one stream synchronisation per forward and gets the error on the forward that overflowed;
         # deferred (default): a non-blocking poll of the forwards that have finished — an overflow surfaces on one of the next
         # forwards (as soon as the host is no longer ahead of it) or at check_finite()

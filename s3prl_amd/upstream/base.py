@@ -45,8 +45,9 @@ class _NoBackward(torch.autograd.Function):
         raise RuntimeError(
             "s3prl_amd upstream experts are inference-only: a gradient reached the hidden states of a training-mode "
             "forward (the reference's `upstream_trainable` / fine-tuning flow), but the HIP encoder has no backward and "
-            "the expert holds no parameters — it would be silently frozen.  Freeze it explicitly (`.eval()` or "
-            "`torch.no_grad()` around the upstream) or fine-tune with the reference s3prl expert")
+            "the expert holds no parameters — it would be silently frozen.  Freeze it explicitly (`expert.freeze()`, "
+            "`.eval()`, `torch.no_grad()` around the upstream, or S3PRL_AMD_TRAIN_MODE=detach) — a Featurizer / head on top "
+            "still gets its gradients — or fine-tune with the reference s3prl expert")
 
 
 class HipUpstreamExpert(torch.nn.Module):
@@ -127,8 +128,34 @@ class HipUpstreamExpert(torch.nn.Module):
         if torch.is_grad_enabled() and any(w.requires_grad for w in wavs):
             raise RuntimeError("s3prl_amd upstream experts are inference-only (no backward through the HIP encoder)")
 
+    # What a TRAINING-MODE forward with autograd on does (the only situation the guard is about).  "raise" (default): the
+    # states carry a node whose backward raises — a fine-tuning flow is told that nothing would be tuned.  "detach": the
+    # states are plain constants and a one-time warning says so — for a parent module that was put in .train() to train a
+    # Featurizer / head on top of a frozen upstream WITHOUT torch.no_grad() around it (s3prl.nn.S3PRLUpstream.__init__ leaves
+    # its expert in train mode, nn/upstream.py:127; with "raise" that flow stops at loss.backward() although it needs no
+    # encoder gradient).  Attribute `train_mode_policy` or env S3PRL_AMD_TRAIN_MODE.
+    train_mode_policy = None
+    _warned_detached = False
+
+    def freeze(self):
+        """Explicitly frozen use, whatever `.train()` calls reach this module later: the states are constants."""
+        self.train_mode_policy = "detach"
+        HipUpstreamExpert._warned_detached = True  # asked for: nothing to warn about
+        return self
+
     def _guard_backward(self, states: torch.Tensor) -> torch.Tensor:
         if self.training and torch.is_grad_enabled():
+            policy = self.train_mode_policy or os.environ.get("S3PRL_AMD_TRAIN_MODE", "raise")
+            if policy == "detach":
+                if not HipUpstreamExpert._warned_detached:
+                    import warnings
+
+                    HipUpstreamExpert._warned_detached = True
+                    warnings.warn("s3prl_amd: training-mode forward of an inference-only upstream — its hidden states are "
+                                  "constants (no gradient reaches the encoder; it holds no parameters)", stacklevel=3)
+                return states
+            if policy != "raise":
+                raise ValueError(f"train_mode_policy / S3PRL_AMD_TRAIN_MODE must be 'raise' or 'detach', not {policy!r}")
             return _NoBackward.apply(states, torch.zeros(0, device=states.device, requires_grad=True))
         return states
 

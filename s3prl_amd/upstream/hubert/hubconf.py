@@ -4,7 +4,8 @@
 ``mhubert_base_vp_en_es_fr_it3``, ``contentvec*``, ``ms_hubert``).  An ``http`` checkpoint resolves to the reference's own
 cache file (``s3prl_amd.download``: ``~/.cache/s3prl/download/<sha256(url)>.<name>``, fetched when absent and a network
 exists); ``fairseq=True`` reads the fairseq checkpoint layout directly (``s3prl_amd.ckpt``); ``legacy=True`` (the
-reference's LegacyUpstreamExpert imports the ``fairseq`` package itself) raises."""
+reference's LegacyUpstreamExpert imports the ``fairseq`` package itself; the released names then select the ORIGINAL
+fairseq file, hubert/hubconf.py:85-96) takes the same route — the file is converted, never handed to ``fairseq``."""
 
 import os
 
@@ -21,13 +22,12 @@ def hubert_custom(ckpt: str, legacy: bool = False, fairseq: bool = False, refres
     assert not (legacy and fairseq), (
         f"{__name__}: pass either legacy=True (load through the fairseq package) or fairseq=True (convert the fairseq "
         "checkpoint first), not both")
-    if legacy:
-        raise NotImplementedError(
-            "hubert: legacy=True loads the checkpoint through the `fairseq` package (LegacyUpstreamExpert), which the "
-            "MI355X path does not depend on — convert the checkpoint (fairseq=True) instead")
     if str(ckpt).startswith("http"):
         ckpt = _urls_to_filepaths(str(ckpt), refresh=refresh)
-    if fairseq:
+    if fairseq or legacy:
+        # legacy=True: the reference hands the ORIGINAL fairseq file to LegacyUpstreamExpert, which needs the `fairseq`
+        # package (hubert/hubconf.py, hubert/expert.py).  The same file is read here without that package: its layout is
+        # exactly what fairseq=True converts, and the hidden states are the same network's.
         ckpt = _convert_fairseq_checkpoint(str(ckpt), "hubert", refresh=refresh)
     assert os.path.isfile(ckpt), ckpt
     return _UpstreamExpert(str(ckpt), **kwargs)

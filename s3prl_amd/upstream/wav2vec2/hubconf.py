@@ -22,13 +22,12 @@ def wav2vec2_custom(ckpt: str, legacy: bool = False, fairseq: bool = False, refr
     assert not (legacy and fairseq), (
         f"{__name__}: pass either legacy=True (load through the fairseq package) or fairseq=True (convert the fairseq "
         "checkpoint first), not both")
-    if legacy:
-        raise NotImplementedError(
-            "wav2vec2: legacy=True loads the checkpoint through the `fairseq` package (LegacyUpstreamExpert), which the "
-            "MI355X path does not depend on — convert the checkpoint (fairseq=True) instead")
     if str(ckpt).startswith("http"):
         ckpt = _urls_to_filepaths(str(ckpt), refresh=refresh)
-    if fairseq:
+    if fairseq or legacy:
+        # legacy=True: the reference hands the ORIGINAL fairseq file to LegacyUpstreamExpert, which needs the `fairseq`
+        # package (wav2vec2/hubconf.py, wav2vec2/expert.py).  The same file is read here without that package: its layout is
+        # exactly what fairseq=True converts, and the hidden states are the same network's.
         ckpt = _convert_fairseq_checkpoint(str(ckpt), "wav2vec2", refresh=refresh)
     assert os.path.isfile(ckpt), ckpt
     return _UpstreamExpert(str(ckpt), **kwargs)

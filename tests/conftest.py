@@ -12,8 +12,35 @@ if ROOT not in sys.path:
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
 
+# Per-test deadline (round 5's last lease died on a host-side infinite loop at test 165 of ~680 and took the rest of the suite
+# with it).  pytest-timeout when it is installed (it is in this image), else faulthandler: a hung test prints every thread's
+# stack and the process exits, instead of holding a GPU lease until gpurun's own limit — which counts as a strike.
+TEST_DEADLINE_S = int(os.environ.get("S3PRL_AMD_TEST_DEADLINE", "180"))
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+    if config.pluginmanager.hasplugin("timeout"):
+        if not config.getoption("timeout", None):  # an explicit --timeout on the command line wins
+            config.option.timeout = TEST_DEADLINE_S
+            config.option.timeout_method = "thread"  # dumps the stacks of all threads, then os._exit: a ctypes call cannot be signalled out of
+        config._s3_deadline = "pytest-timeout"
+    else:
+        config._s3_deadline = "faulthandler"
+
+
+@pytest.hookimpl(hookwrapper=True)
+def pytest_runtest_protocol(item, nextitem):
+    if getattr(item.config, "_s3_deadline", "") == "faulthandler":
+        import faulthandler
+
+        faulthandler.dump_traceback_later(TEST_DEADLINE_S, exit=True)
+        try:
+            yield
+        finally:
+            faulthandler.cancel_dump_traceback_later()
+    else:
+        yield
 
 
 def golden_names(encoder_only=True):

@@ -97,6 +97,27 @@ CASES = {
 }
 
 
+# round 6: the fp16x2 mode's "inside 1e-3" claim on a DISTRIBUTION of weight seeds (round 5: the one extra seed that was tried
+# measured 1.17e-3 on WavLM-large).  Weight seeds 1-6 x five pretrained-like models on 1-2 s ragged inputs (int16-scale PCM with a
+# DC offset where the model does not normalise its waveform), plus WavLM-large seeds 2 and 3 at BASELINE configs[4]'s 15 s
+# ragged shape (seed 1 is `wavlm_large_15s_pl` above).  Same recipe as every other case: the reference expert is executed.
+SEED_MODELS = {  # config -> (subsampling, dc, scale)
+    "hubert_base": ((4, 16), 60.0, 3000.0),
+    "wav2vec2_base": ((4, 16), -35.0, 2000.0),
+    "hubert_large": ((4, 32), 0.0, 1.0),
+    "wavlm_large": ((4, 32), 0.0, 1.0),
+    "data2vec_base": ((4, 16), 0.0, 1.0),
+}
+for _mi, (_m, (_sub, _dc, _sc)) in enumerate(SEED_MODELS.items()):
+    for _s in range(1, 7):
+        _rng = np.random.default_rng(1000 * _mi + _s)
+        _lens = [int(_rng.integers(16000, 32000)), int(_rng.integers(16000, 32000))]
+        CASES[f"{_m}_s{_s}_pl"] = (_m, _s, 100 + 10 * _mi + _s, _lens, _sub, _dc, _sc, {"profile": "pretrained_like", "seed_sweep": True})
+for _s, _short in ((2, 88888), (3, 131071)):
+    CASES[f"wavlm_large_15s_s{_s}_pl"] = ("wavlm_large", _s, 160 + _s, [240000, _short], (16, 32), 0.0, 1.0,
+                                           {"profile": "pretrained_like", "seed_sweep": True})
+
+
 def _import_reference():
     import torch  # noqa: F401
 

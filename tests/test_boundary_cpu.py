@@ -121,8 +121,24 @@ def test_released_name_is_served_from_the_reference_cache_file(tmp_path, monkeyp
         expert = amd.hubert_base(refresh=False)
         assert expert.cfg.to_dict() == cfg.to_dict()
         assert amd.hubert().cfg.to_dict() == cfg.to_dict()                 # the family default = Base (hubconf.py:77-82)
-        with pytest.raises(NotImplementedError, match="fairseq"):
-            amd.hubert_base(legacy=True)
+        # legacy=True selects the ORIGINAL fairseq file (hubert/hubconf.py:85-96); the reference then needs the `fairseq`
+        # package, here the same file goes through the fairseq-layout conversion: a stand-in of that layout at the cache path
+        import torch
+
+        lurl = amd.hubert_base.legacy_url
+        assert lurl == "https://dl.fbaipublicfiles.com/hubert/hubert_base_ls960.pt"
+        with pytest.raises(RuntimeError, match="hubert_base_ls960.pt"):
+            amd.hubert_base(legacy=True)                                   # the legacy file is not in the cache yet
+        lcfg = named_config("tiny_hubert")
+        model_cfg = dict(extractor_mode="default", encoder_layers=3, encoder_embed_dim=128, encoder_ffn_embed_dim=256,
+                         encoder_attention_heads=2, conv_pos=16, conv_pos_groups=4, activation_fn="gelu",
+                         conv_feature_layers=str([tuple(t) for t in lcfg.conv_layers]))
+        torch.save({"cfg": {"task": {"normalize": False, "label_rate": 50.0}, "model": model_cfg},
+                    "model": {k: torch.from_numpy(v) for k, v in synth_weights(lcfg, 4).items()},
+                    "task_state": {"dictionaries": [["a", "b"]]}}, str(download.cache_path(lurl)))
+        legacy = amd.hubert_base(legacy=True)
+        assert legacy.cfg.to_dict() == lcfg.to_dict()
+        assert np.array_equal(legacy._weights["encoder.layers.0.fc1.weight"], synth_weights(lcfg, 4)["encoder.layers.0.fc1.weight"])
         with pytest.raises(NotImplementedError, match="conformer"):
             amd.wav2vec2_conformer_relpos()
         wcfg = named_config("tiny_wavlm")
@@ -156,6 +172,38 @@ def test_fine_tuning_flow_raises_at_backward_instead_of_silently_freezing():
         assert not expert._guard_backward(slab).requires_grad
     expert.eval()
     assert expert._guard_backward(slab) is slab
+
+
+def test_frozen_policy_lets_a_head_train_in_train_mode(monkeypatch):
+    """A parent in `.train()` with no `no_grad` around a FROZEN upstream (s3prl.nn.S3PRLUpstream leaves its expert in train
+    mode, nn/upstream.py:127): `freeze()` / S3PRL_AMD_TRAIN_MODE=detach make the states constants — the head above still gets
+    its gradient — instead of a backward that raises."""
+    import warnings
+
+    import torch
+
+    from s3prl_amd.upstream.base import HipUpstreamExpert
+    from s3prl_amd.synth import named_config, synth_weights
+
+    cfg = named_config("tiny_hubert")
+    expert = HipUpstreamExpert.from_weights(cfg, synth_weights(cfg, 0)).train()
+    slab = torch.ones(4, 2, 5, 8)
+    monkeypatch.setattr(HipUpstreamExpert, "_warned_detached", False)
+    monkeypatch.setenv("S3PRL_AMD_TRAIN_MODE", "detach")
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        a, b = expert._guard_backward(slab), expert._guard_backward(slab)
+    assert a is slab and b is slab and len(rec) == 1 and "constants" in str(rec[0].message)
+    head = torch.nn.Linear(8, 3)
+    head(a).sum().backward()
+    assert head.weight.grad is not None and not a.requires_grad
+    monkeypatch.setenv("S3PRL_AMD_TRAIN_MODE", "raise")
+    assert expert._guard_backward(slab).requires_grad          # back to the default
+    assert expert.freeze() is expert and expert._guard_backward(slab) is slab
+    monkeypatch.setenv("S3PRL_AMD_TRAIN_MODE", "nonsense")
+    expert.train_mode_policy = None
+    with pytest.raises(ValueError, match="raise' or 'detach"):
+        expert._guard_backward(slab)
 
 
 def test_outlier_writer_scaling_touches_only_the_residual_writers():

@@ -417,6 +417,9 @@ PRETRAINED_LIKE = [n for n in golden_names() if n.endswith("_pl")]
 
 def test_pretrained_like_fixtures_are_present():
     assert {"hubert_base_pl", "hubert_large_pl", "wavlm_large_pl", "hubert_base_10s_pl", "wavlm_large_15s_pl"} <= set(PRETRAINED_LIKE)
+    # round 6: the weight-seed sweep (fp32 <= 1e-4 by test_fp32_matches_reference_golden, fp32x3 <= 1e-4 and fp16x2 < 1e-3 below)
+    sweep = {f"{m}_s{s}_pl" for m in ("hubert_base", "wav2vec2_base", "hubert_large", "wavlm_large", "data2vec_base") for s in range(1, 7)}
+    assert sweep | {"wavlm_large_15s_s2_pl", "wavlm_large_15s_s3_pl"} <= set(PRETRAINED_LIKE)
 
 
 @pytest.mark.parametrize("name", PRETRAINED_LIKE)
@@ -447,8 +450,10 @@ def test_16bit_modes_on_pretrained_like_statistics(name, dtype, golden_loader):
     assert np.isfinite(hs).all(), f"{name}/{dtype}: non-finite hidden states"
     ts, cs = meta["t_stride"], meta["c_stride"]
     errs = [O.rel_err(hs[l][:, ::ts, ::cs], golden[l]) for l in range(len(golden))]
-    # (the tiny fixtures' dimensions are below what the fp16x2 hybrids take — C, D < 128: they keep the path's 1e-3)
-    tol = 1e-3 if dtype == "fp16x2" and name.startswith("tiny_") else PL_16BIT_TOL[dtype]
+    # (the tiny fixtures' dimensions are below what the fp16x2 hybrids take — C, D < 128: they keep the path's 1e-3; round 6's
+    # weight-seed sweep — `*_s<seed>_pl`, seeds 1-6 x five models + WavLM-large 15 s seeds 2-3 — is held to the path's tolerance
+    # itself, 1e-3 on EVERY seed: profiles/r06_parity_seeds.md has the distribution)
+    tol = 1e-3 if dtype == "fp16x2" and (name.startswith("tiny_") or meta.get("seed_sweep")) else PL_16BIT_TOL[dtype]
     assert max(errs) < tol, f"{name}/{dtype}: per-layer rel-err {['%.2e' % e for e in errs]}"
     enc.close()
 

@@ -179,8 +179,8 @@ def test_expert_dict_cpu_wavs_and_hub_signatures(tmp_path, golden_loader):
     assert all(h.device.type == "cpu" for h in res["hidden_states"])
     for h, g in zip(res["hidden_states"], golden):
         assert O.rel_err(h.numpy(), g) < 1e-4
-    with pytest.raises(NotImplementedError):
-        hub.hubert_custom(path, legacy=True)
+    with pytest.raises(ValueError, match="not a fairseq checkpoint"):
+        hub.hubert_custom(path, legacy=True)  # legacy=True takes the ORIGINAL fairseq layout (converted here without `fairseq`)
 
 
 def test_wav2vec2_feature_selection_expert(tmp_path, golden_loader):

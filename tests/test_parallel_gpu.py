@@ -179,3 +179,44 @@ def test_cabi_rccl_exchange_world_1():
     with pytest.raises(ValueError):
         comm.gather_layers(hs, overlap_events=events[:2])  # fewer events than states must not reach hipStreamWaitEvent(NULL)
     comm.close()
+
+
+def test_all_pairs_exchange_executes_nccl_send_recv_on_one_gpu():
+    """Round 6: before this test the all-pairs exchange (S3ENC_EXCHANGE_DIRECT) had never executed an ncclSend / ncclRecv — at
+    world 1 comm.hip returned before ncclGroupStart and RCCL refuses two ranks on one device.  Tuning key `comm_self_p2p`: the
+    rank's own block travels as a send-to-self / receive-from-self pair inside the state's group, so the dlopen'ed symbols'
+    signatures, the byte counts / datatype, the group bracketing and the stream order behind the "state l final" events all run
+    for real; same bytes in the same places as the device copy it replaces."""
+    import torch
+
+    from s3prl_amd import _lib
+    from s3prl_amd.parallel import RcclComm
+    from s3prl_amd.synth import named_config, synth_wavs, synth_weights
+    from s3prl_amd.upstream.hubert.expert import UpstreamExpert
+
+    cfg = named_config("tiny_hubert")
+    expert = UpstreamExpert.from_weights(cfg, synth_weights(cfg, 2))
+    wavs = [torch.from_numpy(w).cuda() for w in synth_wavs([4000, 3111, 2345], 9)]
+    lib = _lib.load()
+    comm = RcclComm()
+    enc = expert._encoder_for(wavs[0].device)
+    events = enc.layer_events()
+    try:
+        _lib.check(lib.s3enc_set_tuning(b"comm_self_p2p", 1))
+        for out_dtype in (None, "fp32"):
+            flat = None
+            for _ in range(3):  # repeated: the receive of call i + 1 must not overtake the encoder's writes of call i + 1
+                hs = expert.encode(wavs)
+                if flat is None:
+                    flat = torch.full((hs.shape[0], 2 * hs[0].numel() + 5), float("nan"), device="cuda")
+                    view = flat.as_strided(hs.shape, (flat.stride(0),) + tuple(hs[0].stride()))
+                flat.fill_(float("nan"))
+                comm.gather_layers(hs, overlap_events=events, out=view, algo="direct")
+                torch.cuda.synchronize()
+                assert torch.equal(view, hs) and torch.isnan(flat[:, hs[0].numel():]).all()
+        # without events (ordered behind the caller's stream), contiguous output
+        hs = expert.encode(wavs)
+        assert torch.equal(comm.gather_layers(hs, algo="direct"), hs)
+    finally:
+        _lib.check(lib.s3enc_set_tuning(b"comm_self_p2p", 0))
+        comm.close()
