@@ -14,7 +14,8 @@ every rank (inside the timed region):
   --gather auto        (default) layers for fp32 / fp32x3, layers16 for the 16-bit compute dtypes
   --gather layers      one RCCL all-gather per layer, issued on a side stream as each layer becomes final
   --gather layers16    the same with 16-bit states (bf16 / fp16 compute modes): half the bytes
-  --exchange-algo ring|direct   one all-gather per state, or its all-pairs send / receive form (one peer per xGMI link)
+  --exchange-algo ring|direct|copy   one all-gather per state, its all-pairs send / receive form (one peer per xGMI link), or the
+                                copy-engine form (S3ENC_EXCHANGE_COPY: IPC-mapped slabs + hipMemcpyAsync, no CU, no RCCL; per-state gathers only)
   --gather featurized  the Featurizer's weighted sum runs as the encoder's epilogue; ONE (B, T, D) all-gather
   --gather none        no exchange (what "exposed communication" is measured against)
 --scaling weak (default): --batch utterances per GPU;  --scaling strong: --global-batch utterances split over the ranks.
@@ -171,7 +172,7 @@ def parse_args(argv=None):
     ap.add_argument("--gather", default="auto", choices=["auto", "layers", "layers16", "featurized", "none"],
                     help="auto (default): layers for fp32 / fp32x3, layers16 for the 16-bit compute dtypes (half the xGMI bytes: a "
                          "16-bit step is too short to hide fp32 slabs behind, DESIGN §7)")
-    ap.add_argument("--exchange-algo", default="ring", choices=["ring", "direct"],
+    ap.add_argument("--exchange-algo", default="ring", choices=["ring", "direct", "copy"],
                     help="ring: one all-gather per state (RCCL picks its algorithm); direct: per state one group of all-pairs "
                          "send / receive — xGMI is point-to-point, every peer has its own link (S3ENC_EXCHANGE_DIRECT)")
     ap.add_argument("--exchange-via", default="torch", choices=["torch", "cabi"],
@@ -226,7 +227,8 @@ def dry_run(args, world, rank):
         dist.init_process_group(args.backend if args.backend != "nccl" else "gloo")
     B = args.batch if args.scaling == "weak" else -(-args.global_batch // world)
     hs = torch.full((3, B, 5, 8), float(rank))
-    got = gather_layers(hs, algo=args.exchange_algo) if world > 1 else hs
+    # (the copy-engine form needs device memory: the dry run checks the same layout contract through the collective)
+    got = gather_layers(hs, algo=args.exchange_algo if args.exchange_algo != "copy" else "ring") if world > 1 else hs
     ok = all(bool((got[:, r * B:(r + 1) * B] == r).all()) for r in range(world))
     if world > 1:
         t = torch.tensor([1.0 if ok else 0.0])
@@ -333,7 +335,14 @@ def main():
         gathered = torch.empty((world * B, T, D), dtype=torch.float32, device=dev)
 
     cabi = None
-    if world > 1 and args.exchange_via == "cabi" and gather in ("layers", "layers16"):
+    copyc = None
+    if world > 1 and args.exchange_algo == "copy":
+        if gather not in ("layers", "layers16"):
+            raise SystemExit("--exchange-algo copy moves the per-state slabs (--gather layers / layers16)")
+        from s3prl_amd.parallel import CopyComm
+
+        copyc = CopyComm(device=dev.index)  # the IPC handles travel over the existing process group (any backend)
+    elif world > 1 and args.exchange_via == "cabi" and gather in ("layers", "layers16"):
         from s3prl_amd.parallel import RcclComm
 
         cabi = RcclComm(device=dev.index)  # the 128-byte RCCL id travels over the existing process group
@@ -353,7 +362,9 @@ def main():
             if exchange and gather != "none":
                 # one all-gather per layer (hidden_states[l] stays a contiguous (B_global, T, D) block), issued on a
                 # side stream as soon as layer l is final so it overlaps the remaining layers' compute
-                if cabi is not None:
+                if copyc is not None:
+                    copyc.gather_layers(hs, overlap_events=events)  # (into the slab CopyComm registered for this shape)
+                elif cabi is not None:
                     cabi.gather_layers(hs, overlap_events=events, out=gathered, algo=args.exchange_algo)
                 else:
                     gather_layers(hs, overlap_events=events, out=gathered, algo=args.exchange_algo)
@@ -448,7 +459,7 @@ def main():
             per_state = B * T * D * (2 if gather == "layers16" else 4)
             recv = 0 if gather == "none" else (world - 1) * per_state * (1 if gather == "featurized" else NS)
             comm = {"mode": gather, "algo": args.exchange_algo if gather != "none" else None,
-                    "via": (args.exchange_via if gather in ("layers", "layers16") else "torch") if gather != "none" else None,
+                    "via": (("cabi" if args.exchange_algo == "copy" else args.exchange_via) if gather in ("layers", "layers16") else "torch") if gather != "none" else None,
                     "bytes_received_per_gpu_per_step": int(recv),
                     "ms_per_step_without_exchange": round(el2 / k2 * 1e3, 3),
                     "exposed_ms_per_step": round((elapsed / steps - el2 / k2) * 1e3, 3),

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define S3ENC_VERSION 6
+#define S3ENC_VERSION 7
 #define S3ENC_MAX_CONV 16
 #define S3ENC_MAX_RES 4 /* resolutions of a multires-HuBERT U-net: up to 3 rate pairs, 7 encoder blocks */
 
@@ -213,6 +213,20 @@ int s3enc_comm_allgather_states(s3enc_comm c, const void* send, int64_t send_sta
  * Identical result bytes; replaces nothing in the reference (see above).  With world = 1 both are one device copy. */
 #define S3ENC_EXCHANGE_COLLECTIVE 0
 #define S3ENC_EXCHANGE_DIRECT 1
+/* S3ENC_EXCHANGE_COPY (ABI 7): the same bytes in the same places moved by the COPY ENGINES — no RCCL kernel, no compute unit beside
+ * the encoder's GEMMs.  Every rank registers ONE receive slab (s3enc_comm_copy_export: the `recv` of every later exchange), the ranks
+ * swap the S3ENC_COPY_HANDLE_BYTES blobs by any side channel (hipIpcGetMemHandle inside: one PROCESS per GPU) and map each other's slab
+ * and mailbox (s3enc_comm_copy_attach).  Per exchange and peer: one hipMemcpyAsync per state into the peer's slab, on that peer's own
+ * stream (all xGMI links at once) and behind the encoder's "state l final" event; two 64-bit sequence numbers per pair order the
+ * exchange (ready-to-receive, data-has-landed; csrc/comm.hip).  The waits are one-wave polls with a deadline (S3ENC_COPY_DEADLINE_MS,
+ * default 5000): s3enc_comm_copy_status reports a missed one instead of a hung GPU.  A communicator for this form alone needs no RCCL:
+ * s3enc_comm_init_local. */
+#define S3ENC_EXCHANGE_COPY 2
+#define S3ENC_COPY_HANDLE_BYTES 256
+int s3enc_comm_init_local(int32_t world, int32_t rank, int32_t device, s3enc_comm* out);
+int s3enc_comm_copy_export(s3enc_comm c, void* recv_slab, int64_t bytes, void* handle_out);
+int s3enc_comm_copy_attach(s3enc_comm c, const void* handles /* world x S3ENC_COPY_HANDLE_BYTES, in rank order */);
+int s3enc_comm_copy_status(s3enc_comm c, int32_t* status);
 int s3enc_comm_exchange_states(s3enc_comm c, int32_t algo, const void* send, int64_t send_state_stride, void* recv,
                                int64_t recv_state_stride, int32_t n_states, int64_t bytes_per_state, void* const* ready_events,
                                void* stream);
@@ -273,6 +287,9 @@ int s3enc_debug_clock_sample(uint64_t* out3_device, void* stream);
  *                   widening needs a new handle);
  *   "comm_self_p2p": S3ENC_EXCHANGE_DIRECT test hook: 1 = a rank's own block travels as an ncclSend-to-self / ncclRecv-from-self pair
  *                   inside the state's group instead of a device copy (how the all-pairs code executes on a one-GPU box); default 0;
+ *   "attn_persist": 16-bit modes: 1 (default) = the attention kernel runs as persistent workgroups that fetch the next (batch, head,
+ *                   query block) item's operands under the current item's last key tile, 0 = the one-shot grid of rounds 1-5; results
+ *                   are bit-identical;
  *   "reserve_cus":  CUs the persistent one-workgroup-per-CU GEMM of the 16-bit modes leaves out of its grid (default 0; a measurement
  *                   knob — leaving CUs to a collective's channel kernels costs more than sharing them: profiles/r05_cu_contention.md);
  *   "conv0_nt":     1 (default) = the fp32 conv0 kernel writes its activation with non-temporal stores, 0 = plain stores;

@@ -23,7 +23,9 @@ FAMILY = {"hubert": 0, "wav2vec2": 1, "wavlm": 2, "distiller": 3, "multires_hube
 SEL_HIDDEN, SEL_LAYER_OUT, SEL_FFN_OUT = 0, 1, 2
 SELECTIONS = {None: SEL_HIDDEN, "hidden_states": SEL_HIDDEN, "fairseq_layers": SEL_LAYER_OUT,
               "fairseq_layers_before_residual": SEL_FFN_OUT}
-ABI_VERSION = 6
+ABI_VERSION = 7
+EXCHANGE_COLLECTIVE, EXCHANGE_DIRECT, EXCHANGE_COPY = 0, 1, 2   # S3ENC_EXCHANGE_*
+COPY_HANDLE_BYTES = 256                                         # S3ENC_COPY_HANDLE_BYTES
 
 
 class S3Config(C.Structure):
@@ -88,6 +90,10 @@ _PROTOS = {
     "s3enc_comm_allgather_states": (C.c_int, [_VP, _VP, _I64, _VP, _I64, _I32, _I64, C.POINTER(_VP), _VP]),
     "s3enc_comm_exchange_states": (C.c_int, [_VP, _I32, _VP, _I64, _VP, _I64, _I32, _I64, C.POINTER(_VP), _VP]),
     "s3enc_comm_destroy": (C.c_int, [_VP]),
+    "s3enc_comm_init_local": (C.c_int, [_I32, _I32, _I32, C.POINTER(_VP)]),
+    "s3enc_comm_copy_export": (C.c_int, [_VP, _VP, _I64, _VP]),
+    "s3enc_comm_copy_attach": (C.c_int, [_VP, _VP]),
+    "s3enc_comm_copy_status": (C.c_int, [_VP, C.POINTER(_I32)]),
     "s3enc_set_handle_tuning": (C.c_int, [_VP, C.c_char_p, _I32]),
     "s3enc_set_tuning": (C.c_int, [C.c_char_p, _I32]),
     "s3enc_op_gemm": (C.c_int, [_I32, _VP, _I64, _I64, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _VP, _VP, _VP, _VP,

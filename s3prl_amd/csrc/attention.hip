@@ -13,6 +13,7 @@
 // fp32 path: v_mfma_f32_32x32x2_f32 (exact);  16-bit path: v_mfma_f32_32x32x16_{bf16,f16} with V staged
 // transposed in LDS.  Padded queries are computed like the reference does; keys beyond
 // valid[b] are skipped tile-wise and masked inside the last tile.
+#include <algorithm>
 #include <type_traits>
 
 #include "kernels.h"
@@ -224,6 +225,214 @@ __global__ __launch_bounds__(256, 3) void attn_f32_kernel(AttnParams p) {
         for (int g = 0; g < 4; ++g) {
             *(float4*)(op + 8 * g) = make_float4(o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
             *(float4*)(op + 32 + 8 * g) = make_float4(o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+        }
+    }
+}
+
+// ---- round 6: the persistent form of the fp32 kernel (the headline mode's attention) ---------------------------------------------
+// Same arithmetic in the same order as attn_f32_kernel (bit-identical), the life cycle of attn_h16p_kernel below: 3 resident
+// workgroups per CU walk the (batch, head, query block) items of their XCD; the next item's first K / V tile rides in the staging
+// registers under the current item's last tile and its Q fragment is fetched while the current item's result is normalised and
+// stored.  The fp32 kernel moves twice the bytes of the 16-bit one (147 MB of q|k|v in, 49 MB out per HuBERT-base launch): with a
+// one-shot grid every workgroup of a round loads, multiplies and stores in phase and ~17 % of the launch has no MFMA to issue
+// (mfma_busy 0.83, profiles/r05_pmc_fp32.md).
+__global__ __launch_bounds__(256, 3) void attn_f32p_kernel(AttnParams p) {
+    __shared__ __attribute__((aligned(16))) float Ks[2 * KT * KS32];
+    __shared__ __attribute__((aligned(16))) float Vs[2 * KT * KS32];
+    extern __shared__ float bias_s[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int D = p.H * HD, ldi = 3 * D;
+    const int nqb = (p.T + QT - 1) / QT;
+    const int xcd = blockIdx.x & 7, wpx = gridDim.x >> 3;  // (the launcher's grid is a multiple of 8)
+    const int units = p.B * p.H;
+    const int n_items = (units > xcd ? (units - xcd + 7) / 8 : 0) * nqb;
+    int it = blockIdx.x >> 3;
+    if (it >= n_items) return;
+
+    struct Item {
+        const float* base;  // this (batch, head)'s q row 0
+        int b, head, qb;
+    };
+    auto item_of = [&](int i) {
+        Item w;
+        const int unit = xcd + 8 * (i / nqb);
+        w.qb = i % nqb;
+        w.b = unit / p.H;
+        w.head = unit % p.H;
+        w.base = (const float*)p.qkv + (long)w.b * p.T * ldi + w.head * HD;
+        return w;
+    };
+    // rows 0 .. T - 1 of the item's (batch, head) behind a buffer descriptor: one constant 32-bit byte offset per lane and load, the
+    // tile index in the scalar offset; rows past the last frame read as ZERO (their scores are masked: P = 0 meets V = 0)
+    auto rsrc_of = [&](const Item& w) {
+        return __builtin_amdgcn_make_buffer_rsrc((void*)w.base, 0, (p.T * ldi - w.head * HD) * 4, 0x00020000);
+    };
+    const int srow = tid >> 4, sc4 = tid & 15;  // staging: rows srow and srow + 16, float4 column sc4
+    const unsigned tstride_b = (unsigned)(KT * ldi * 4);
+    const unsigned so0 = (unsigned)((srow * ldi + sc4 * 4) * 4), so1 = so0 + (unsigned)(16 * ldi * 4);
+    f32x4 kreg[2], vreg[2];
+    auto load_tile = [&](const __amdgpu_buffer_rsrc_t& rs, int kt) {
+        const unsigned so = (unsigned)kt * tstride_b;
+        kreg[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, so0 + (unsigned)(D * 4), so, 0));
+        vreg[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, so0 + (unsigned)(2 * D * 4), so, 0));
+        kreg[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, so1 + (unsigned)(D * 4), so, 0));
+        vreg[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, so1 + (unsigned)(2 * D * 4), so, 0));
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *(f32x4*)(Ks + buf * KT * KS32 + (srow + 16 * i) * KS32 + sc4 * 4) = kreg[i];
+            *(f32x4*)(Vs + buf * KT * KS32 + (srow + 16 * i) * KS32 + sc4 * 4) = vreg[i];
+        }
+    };
+
+    Item cur = item_of(it);
+    float qf[32];
+    int q_g, q_c, valid, ntiles, bias_off;
+    float gate = 1.f;
+    const float* btab = nullptr;
+    auto enter_scalars = [&](const Item& w) {
+        q_g = w.qb * QT + wave * 32 + l31;
+        q_c = q_g < p.T ? q_g : p.T - 1;
+        valid = p.valid[w.b];
+        ntiles = (valid + KT - 1) / KT;
+        bias_off = w.qb * QT + QT - 1;  // window index = (key - query) + bias_off
+    };
+    auto load_q = [&](const __amdgpu_buffer_rsrc_t& rs) {  // B operand: lane (q, half) holds Q[q][half * 32 + s], s = 0 .. 31
+        const unsigned qo = (unsigned)((q_c * ldi + half * 32) * 4);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, qo + 16 * i, 0, 0));
+            qf[4 * i] = t[0];
+            qf[4 * i + 1] = t[1];
+            qf[4 * i + 2] = t[2];
+            qf[4 * i + 3] = t[3];
+        }
+    };
+    auto enter_bias = [&](const Item& w) {  // WavLM: the item's window of its head's table (see attn_f32_kernel) + the query's gate
+        if (p.bias_table) {
+            const int R = p.table_R;
+            const float* src = p.bias_table + (long)w.head * (2 * R + 1) + R;
+            const int rel0 = -(w.qb * QT + QT - 1);
+            for (int i = threadIdx.x; i < p.T + QT - 1 + BIAS_PAD; i += 256) bias_s[i] = src[min(max(rel0 + i, -R), R)];
+            btab = bias_s;
+            gate = p.gate ? p.gate[((long)w.b * p.H + w.head) * p.T + q_c] : 1.f;
+        }
+    };
+    enter_scalars(cur);
+    __amdgpu_buffer_rsrc_t rs_cur = rsrc_of(cur);
+    load_q(rs_cur);
+    enter_bias(cur);
+    load_tile(rs_cur, 0);
+    store_tile(0);
+    __syncthreads();
+    int buf = 0;  // the LDS buffer the next tile to multiply sits in (runs on across items)
+
+    f32x16 o0, o1;
+    while (true) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o0[r] = o1[r] = 0.f;
+        float m_run = -INFINITY, l_run = 0.f;
+        const int nxt = it + wpx;
+        const bool has_next = nxt < n_items;
+        Item nx = cur;
+        if (ntiles == 0 && has_next) {  // (an utterance without a single valid frame: nothing to multiply, the hand-over still happens)
+            nx = item_of(nxt);
+            rs_cur = rsrc_of(nx);
+            load_tile(rs_cur, 0);
+        }
+        for (int kt = 0; kt < ntiles; ++kt) {
+            if (kt + 1 < ntiles) {
+                load_tile(rs_cur, kt + 1);
+            } else if (has_next) {  // the next item's first tile rides in the staging registers under this item's last tile
+                nx = item_of(nxt);
+                rs_cur = rsrc_of(nx);
+                load_tile(rs_cur, 0);
+            }
+            const float* Kb = Ks + buf * KT * KS32;
+            const float* Vb = Vs + buf * KT * KS32;
+            f32x16 s;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
+            const float* kp = Kb + l31 * KS32 + half * 32;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float4 kf = *(const float4*)(kp + 4 * i);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[4 * i], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[4 * i + 1], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[4 * i + 2], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[4 * i + 3], s, 0, 0, 0);
+            }
+            if (btab) {
+                const float* bb = btab + (kt * KT + 4 * half - q_c + bias_off);  // branch-free, see attn_f32_kernel
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[r] = fmaf(gate, bb[(r & 3) + 8 * (r >> 2)], s[r]);
+            }
+            if (kt * KT + KT > valid) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[r] = kt * KT + crow(r, half) < valid ? s[r] : -INFINITY;
+            }
+            float mx = s[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+            mx = xhalf_max(mx);
+            if (__any(mx > m_run + 8.f)) {
+                const float m_new = fmaxf(m_run, mx);
+                const float alpha = __expf(m_run - m_new);
+                l_run *= alpha;
+                m_run = m_new;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    o0[r] *= alpha;
+                    o1[r] *= alpha;
+                }
+            }
+            float ps = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                s[r] = __expf(s[r] - m_run);
+                ps += s[r];
+            }
+            l_run += ps;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float* vp = Vb + crow(r, half) * KS32 + l31;
+                o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[0], s[r], o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[32], s[r], o1, 0, 0, 0);
+            }
+            if (kt + 1 < ntiles) {
+                store_tile(buf ^ 1);
+                __syncthreads();
+                buf ^= 1;
+            }
+        }
+        // ---- seam: this item's result goes out while the next item's operands come in ----
+        const float inv = 1.f / xhalf_sum(l_run);
+        const bool q_ok = q_g < p.T;
+        const long obase = (long)cur.b * p.T * D + cur.head * HD;  // (wave-uniform)
+        const unsigned orow = (unsigned)(q_g * D + 4 * half);
+        if (has_next) {
+            store_tile(buf ^ 1);  // (frees the staging registers)
+            enter_scalars(nx);    // (q_g / q_c / valid / ntiles now belong to the next item)
+            load_q(rs_cur);       // lands under the normalisation and the stores below
+        }
+        if (q_ok) {
+            float* op = (float*)p.out + obase + orow;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                *(float4*)(op + 8 * g) = make_float4(o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
+                *(float4*)(op + 32 + 8 * g) = make_float4(o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+            }
+        }
+        if (!has_next) break;
+        __syncthreads();  // every wave is past its last tile: the other K / V buffer (and the bias window) may be re-used
+        buf ^= 1;
+        it = nxt;
+        cur = nx;
+        if (p.bias_table) {
+            enter_bias(cur);
+            __syncthreads();
         }
     }
 }
@@ -486,6 +695,286 @@ __global__ __launch_bounds__(256, BIAS ? 2 : 3) void attn_h16_kernel(AttnParams 
     }
 }
 
+// ---- round 6: the persistent form of the 16-bit kernel ----------------------------------------------------------------------
+// Same tile body as attn_h16_kernel (bit-identical results: the per-accumulator order of every MFMA and every softmax update is
+// unchanged), different life cycle.  The one-shot grid is phase-locked: all 768 resident workgroups load their Q and first K / V
+// tile in the same microseconds (the memory system saturated, the matrix pipe idle), multiply in the same microseconds (the other
+// way round) and store together; a second round repeats it — an EMPTY key loop was 21.6 of 46.5 us (profiles/r05_attn_lab.md), of
+// which ~15 us is simply the 74 MB of Q / first tiles / outputs moving while nothing multiplies.  Here 3 (BIAS: 2) workgroups per
+// CU stay resident and walk the (batch, head, query block) items of their XCD; the NEXT item's first K / V tile is loaded into the
+// staging registers in front of the current item's LAST tile, its Q fragments right behind that tile, and both land under the
+// current item's last MFMAs, its normalisation and its output stores: after the first item a workgroup never waits for a cold
+// prologue again, and the output stores of item i drain under the key loop of item i + 1.
+// XCD-aware item order (as attn_work): XCD x owns the units u = x (mod 8); its workgroups take that XCD's items (unit-major, the
+// query blocks of a unit adjacent) round-robin, so the co-resident workgroups of an XCD work on the same few units and K / V
+// come from HBM once.
+template <typename T, bool BIAS>
+__global__ __launch_bounds__(256, BIAS ? 2 : 3) void attn_h16p_kernel(AttnParams p) {
+    __shared__ __attribute__((aligned(16))) u16 Ks[2 * KBUF16];
+    __shared__ __attribute__((aligned(16))) u16 Vt[2 * VBUF16];
+    extern __shared__ float bias_s[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int D = p.H * HD;
+    const long ld = 3L * D;
+    const int nqb = (p.T + QT - 1) / QT;
+    const int xcd = blockIdx.x & 7, wpx = gridDim.x >> 3;  // (the launcher's grid is a multiple of 8)
+    const int units = p.B * p.H;
+    const int n_items = (units > xcd ? (units - xcd + 7) / 8 : 0) * nqb;
+    int it = blockIdx.x >> 3;
+    if (it >= n_items) return;
+
+    // staging roles: K — rows (tid>>3) and +32, 16-byte chunk tid&7;  V — key pair tid&31, dim group tid>>5.
+    // Loads go through a buffer descriptor of the item's (batch, head) slab — base and extent in SGPRs — with ONE constant 32-bit byte
+    // offset per lane and load; the tile index rides in the scalar offset.  (The one-shot kernel's four 64-bit row pointers, turned
+    // into per-tile pointer chains and hoisted out of the item loop together with every clamped row x stride product, cost this
+    // kernel 99 spilled registers.)  Rows past the last frame are out of the descriptor's range and read as ZERO — their scores are
+    // masked to -inf, so P = 0 meets V = 0; the one-shot kernel re-reads the last frame for the same purpose.
+    const int krow = tid >> 3, kc8 = tid & 7;
+    const int vj = tid & 31, vdg = tid >> 5;
+    u32x4 kreg[2], vreg[2];
+    const int ldi = 3 * D;
+    const unsigned tstride_b = (unsigned)(KT16 * ldi * 2);                       // bytes between consecutive tiles
+    const unsigned ko0 = (unsigned)((krow * ldi + D + kc8 * 8) * 2), ko1 = ko0 + (unsigned)(32 * ldi * 2);
+    const unsigned vo0 = (unsigned)((2 * vj * ldi + 2 * D + vdg * 8) * 2), vo1 = vo0 + (unsigned)(ldi * 2);
+    auto load_tile = [&](const __amdgpu_buffer_rsrc_t& rs, int kt) {
+        const unsigned so = (unsigned)kt * tstride_b;
+        kreg[0] = __builtin_amdgcn_raw_buffer_load_b128(rs, ko0, so, 0);
+        kreg[1] = __builtin_amdgcn_raw_buffer_load_b128(rs, ko1, so, 0);
+        vreg[0] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo0, so, 0);
+        vreg[1] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo1, so, 0);
+    };
+    u16* const ks_st = Ks + krow * KS16 + kc8 * 8;
+    u16* const vt_st = Vt + (vdg * 8) * VS16 + 2 * vj;
+    auto store_tile = [&](int buf) {
+        u16* ks_ = ks_st + buf * KBUF16;
+        u16* vt_ = vt_st + buf * VBUF16;
+        *(u32x4*)ks_ = kreg[0];
+        *(u32x4*)(ks_ + 32 * KS16) = kreg[1];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned a_ = vreg[0][i], b_ = vreg[1][i];
+            *(unsigned*)(vt_ + (2 * i) * VS16) = (a_ & 0xffffu) | (b_ << 16);
+            *(unsigned*)(vt_ + (2 * i + 1) * VS16) = (a_ >> 16) | (b_ & 0xffff0000u);
+        }
+    };
+    const u16* const kf_rd = Ks + l31 * KS16 + 8 * half;
+    const u16* const vf_rd = Vt + l31 * VS16 + 4 * half;
+
+    // ---- the current item ----
+    struct Item {
+        const u16* base;  // this (batch, head)'s q row 0
+        int b, head, qb;
+    };
+    auto rsrc_of = [&](const Item& w) {  // rows 0 .. T - 1 of the item's (batch, head): [q | k | v] at a stride of 3D elements
+        return __builtin_amdgcn_make_buffer_rsrc((void*)w.base, 0, (p.T * ldi - w.head * HD) * 2, 0x00020000);
+    };
+    auto item_of = [&](int i) {
+        Item w;
+        const int unit = xcd + 8 * (i / nqb);
+        w.qb = i % nqb;
+        w.b = unit / p.H;
+        w.head = unit % p.H;
+        w.base = (const u16*)p.qkv + (long)w.b * p.T * ld + w.head * HD;
+        return w;
+    };
+    Item cur = item_of(it);
+    uint4 qf[4];
+    int q_g, q_c, valid, ntiles, bias_off;
+    float gate2 = 1.44269504088896340736f;
+    const float* btab = nullptr;
+    auto enter_scalars = [&](const Item& w) {  // everything of an item but its Q fragments and its first tile
+        q_g = w.qb * QT + wave * 32 + l31;
+        q_c = q_g < p.T ? q_g : p.T - 1;
+        valid = p.valid[w.b];
+        ntiles = (valid + KT16 - 1) / KT16;
+        bias_off = w.qb * QT + QT - 1;  // window index = (key - query) + bias_off
+    };
+    auto load_q = [&](const __amdgpu_buffer_rsrc_t& rs) {
+        const unsigned qo = (unsigned)((q_c * ldi + 8 * half) * 2);
+#pragma unroll
+        for (int st = 0; st < 4; ++st) qf[st] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, qo + st * 32, 0, 0));
+    };
+    auto enter_bias = [&](const Item& w) {  // WavLM: the item's window of its head's table (see attn_h16_kernel) + the query's gate
+        if (BIAS && p.bias_table) {
+            const int R = p.table_R;
+            const float* src = p.bias_table + (long)w.head * (2 * R + 1) + R;
+            const int rel0 = -(w.qb * QT + QT - 1);
+            for (int i = threadIdx.x; i < p.T + QT - 1 + BIAS_PAD; i += 256) bias_s[i] = src[min(max(rel0 + i, -R), R)];
+            btab = bias_s;
+            gate2 = (p.gate ? p.gate[((long)w.b * p.H + w.head) * p.T + q_c] : 1.f) * 1.44269504088896340736f;
+        }
+    };
+    enter_scalars(cur);
+    __amdgpu_buffer_rsrc_t rs_cur = rsrc_of(cur);
+    load_q(rs_cur);
+    enter_bias(cur);
+    load_tile(rs_cur, 0);
+    store_tile(0);
+    __syncthreads();
+    int buf = 0;  // the LDS buffer the next tile to multiply sits in (runs on across items)
+
+    f32x16 o0, o1, negm;
+    float l_run;
+    bool first;
+    while (true) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o0[r] = o1[r] = negm[r] = 0.f;
+        l_run = 0.f;
+        first = true;
+
+        // one 64-key tile.  FULL: every key is valid (all tiles but the last)
+        auto tile = [&](auto full_c, int kt) {
+            constexpr bool FULL = decltype(full_c)::value;
+            const u16* ks = kf_rd + buf * KBUF16;
+            const u16* vt = vf_rd + buf * VBUF16;
+            const bool two = FULL || kt * KT16 + 32 < valid;  // wave-uniform: the second half has at least one valid key
+            auto scores = [&](int h) {
+                f32x16 sc = negm;
+                if (S3_PROBE(p, 8)) return sc;
+#pragma unroll
+                for (int st = 0; st < 4; ++st) {
+                    const uint4 kf = *(const uint4*)(ks + h * 32 * KS16 + st * 16);
+                    sc = Mma16<T>::run(kf, qf[st], sc);
+                }
+                return sc;
+            };
+            auto half_step = [&](f32x16& sc, int h) {
+                const int k0_ = kt * KT16 + h * 32;
+                if (BIAS && btab) {
+                    const float* bb = btab + (k0_ + 4 * half - q_c + bias_off);  // branch-free, see attn_f32_kernel
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sc[r] = fmaf(gate2, bb[(r & 3) + 8 * (r >> 2)], sc[r]);
+                }
+                if (!FULL && k0_ + 32 > valid) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sc[r] = k0_ + crow(r, half) < valid ? sc[r] : -INFINITY;
+                }
+                if (S3_PROBE(p, 2)) goto pv;
+                {
+                float mx = __builtin_amdgcn_fmed3f(sc[0], sc[1], INFINITY);
+#pragma unroll
+                for (int r = 2; r < 16; ++r) mx = __builtin_amdgcn_fmed3f(mx, sc[r], INFINITY);
+                mx = xhalf_max(mx);
+                if (__builtin_expect(first || __any(mx > 8.f), 0)) {
+                    const float delta = first ? mx : fmaxf(mx, 0.f);
+                    const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);  // (first: see attn_h16_kernel)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        o0[r] *= alpha;
+                        o1[r] *= alpha;
+                        sc[r] -= delta;
+                        negm[r] -= delta;
+                    }
+                    l_run *= alpha;
+                    first = false;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sc[r] = __builtin_amdgcn_exp2f(sc[r]);
+                {
+                    float ps0 = sc[0] + sc[1], ps1 = sc[2] + sc[3];
+#pragma unroll
+                    for (int r = 4; r < 16; r += 4) {
+                        ps0 += sc[r] + sc[r + 1];
+                        ps1 += sc[r + 2] + sc[r + 3];
+                    }
+                    l_run += ps0 + ps1;
+                }
+                }
+            pv:
+                if (S3_PROBE(p, 4)) {
+                    l_run += sc[0] + sc[5] + sc[11];
+                    return;
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    uint4 pf;
+                    pf.x = Cvt<T>::pack2(sc[8 * u + 0], sc[8 * u + 1]);
+                    pf.y = Cvt<T>::pack2(sc[8 * u + 2], sc[8 * u + 3]);
+                    pf.z = Cvt<T>::pack2(sc[8 * u + 4], sc[8 * u + 5]);
+                    pf.w = Cvt<T>::pack2(sc[8 * u + 6], sc[8 * u + 7]);
+                    const u16* v0 = vt + 32 * h + 16 * u;
+                    const uint2 a00 = *(const uint2*)(v0), a01 = *(const uint2*)(v0 + 8);
+                    const uint2 a10 = *(const uint2*)(v0 + 32 * VS16), a11 = *(const uint2*)(v0 + 32 * VS16 + 8);
+                    o0 = Mma16<T>::run(make_uint4(a00.x, a00.y, a01.x, a01.y), pf, o0);
+                    o1 = Mma16<T>::run(make_uint4(a10.x, a10.y, a11.x, a11.y), pf, o1);
+                }
+            };
+            f32x16 sc = scores(0);
+            half_step(sc, 0);
+            if (two) {
+                sc = scores(1);
+                half_step(sc, 1);
+            }
+        };
+
+        const int nxt = it + wpx;
+        const bool has_next = nxt < n_items;
+        Item nx = cur;
+        if (ntiles == 0 && has_next) {  // (an utterance without a single valid frame: nothing to multiply, the hand-over still happens)
+            nx = item_of(nxt);
+            rs_cur = rsrc_of(nx);
+            load_tile(rs_cur, 0);
+        }
+        for (int kt = 0; kt < ntiles; ++kt) {
+            if (kt + 1 < ntiles) {
+                if (!S3_PROBE(p, 1)) load_tile(rs_cur, kt + 1);
+                tile(std::true_type{}, kt);
+                if (!S3_PROBE(p, 1)) store_tile(buf ^ 1);
+            } else {
+                if (has_next) {  // the next item's first tile rides in the staging registers under this item's last tile
+                    nx = item_of(nxt);
+                    rs_cur = rsrc_of(nx);
+                    load_tile(rs_cur, 0);
+                }
+                tile(std::false_type{}, kt);
+            }
+            if (kt + 1 < ntiles) {
+                if (!S3_PROBE(p, 16)) __syncthreads();
+                buf ^= 1;
+            }
+        }
+        // ---- seam: this item's result goes out while the next item's operands come in ----
+        const float inv = 1.f / xhalf_sum(l_run);
+        const bool q_ok = q_g < p.T;
+        const long obase = (long)cur.b * p.T * D + cur.head * HD;  // (wave-uniform)
+        const unsigned orow = (unsigned)(q_g * D + 4 * half);
+        if (has_next) {
+            store_tile(buf ^ 1);  // (frees the staging registers)
+            enter_scalars(nx);    // (q_g / q_c / valid / ntiles now belong to the next item)
+            load_q(rs_cur);       // lands under the normalisation and the stores below
+        }
+        if (p.out_f32) {  // (workgroup-uniform)
+            if (q_ok) {
+                float* op = (float*)p.out + obase + orow;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    *(float4*)(op + 8 * g) = make_float4(o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
+                    *(float4*)(op + 32 + 8 * g) = make_float4(o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+                }
+            }
+        } else if (q_ok) {
+            u16* op = (u16*)p.out + obase + orow;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                *(uint2*)(op + 8 * g) = make_uint2(Cvt<T>::pack2(o0[4 * g] * inv, o0[4 * g + 1] * inv),
+                                                   Cvt<T>::pack2(o0[4 * g + 2] * inv, o0[4 * g + 3] * inv));
+                *(uint2*)(op + 32 + 8 * g) = make_uint2(Cvt<T>::pack2(o1[4 * g] * inv, o1[4 * g + 1] * inv),
+                                                        Cvt<T>::pack2(o1[4 * g + 2] * inv, o1[4 * g + 3] * inv));
+            }
+        }
+        if (!has_next) break;
+        __syncthreads();  // every wave is past its last tile: the other K / V buffer (and the bias window) may be re-used
+        buf ^= 1;
+        it = nxt;
+        cur = nx;
+        if (BIAS && p.bias_table) {
+            enter_bias(cur);
+            __syncthreads();
+        }
+    }
+}
+
 // WavLM gate from the layer input split into heads (wavlm/modules.py:535-549):
 //   g = sigmoid( sum4( grep_linear(x_head) ) ) -> (a, b);  gate = a * (b * grep_a[h] - 1) + 2
 // ---- fp32x3 mode (S3ENC_F32X3): fp32 q|k|v in, fp32 out, both matrix products on split bf16 operands ------------------
@@ -716,15 +1205,43 @@ hipError_t launch_attention(int dtype, const AttnParams& p, hipStream_t s) {
     const size_t dyn = p.bias_table ? (size_t)(p.T + QT - 1 + BIAS_PAD) * sizeof(float) : 0;  // the workgroup's table window
     if (dyn > 24 * 1024) return hipErrorInvalidValue;  // T <= 6017 frames (120 s): the window must fit beside K/V (engine checks)
     switch (dtype) {
-        case F32: hipLaunchKernelGGL(attn_f32_kernel, grid, block, dyn, s, p); break;
+        case F32:
+            if (tuning().attn_persist) {
+                const long items8 = (long)units8 * ((p.T + QT - 1) / QT);  // items of the fullest XCD
+                const long wpx = std::min<long>(items8, 32L * 3);          // 32 CUs per XCD, 3 resident workgroups per CU
+                hipLaunchKernelGGL(attn_f32p_kernel, dim3((unsigned)(8 * wpx)), block, dyn, s, p);
+            } else {
+                hipLaunchKernelGGL(attn_f32_kernel, grid, block, dyn, s, p);
+            }
+            break;
         case BF16:
-            if (p.bias_table) hipLaunchKernelGGL((attn_h16_kernel<bf16_tag, true>), grid, block, dyn, s, p);
-            else hipLaunchKernelGGL((attn_h16_kernel<bf16_tag, false>), grid, block, dyn + tuning().attn_lds_pad, s, p);
+        case F16: {
+            const bool bf = dtype == BF16, bias = p.bias_table != nullptr;
+            if (tuning().attn_persist) {
+                // persistent workgroups: 3 (BIAS: 2) per CU — what __launch_bounds__ guarantees registers for — but never more
+                // than the XCD's share of items needs (a grid of idle workgroups is not free)
+                const int per_cu = bias ? 2 : 3;
+                const long items8 = (long)units8 * ((p.T + QT - 1) / QT);  // items of the fullest XCD
+                const long wpx = std::min<long>(items8, 32L * per_cu);     // 32 CUs per XCD
+                dim3 pgrid((unsigned)(8 * wpx));
+                if (bf) {
+                    if (bias) hipLaunchKernelGGL((attn_h16p_kernel<bf16_tag, true>), pgrid, block, dyn, s, p);
+                    else hipLaunchKernelGGL((attn_h16p_kernel<bf16_tag, false>), pgrid, block, dyn + tuning().attn_lds_pad, s, p);
+                } else {
+                    if (bias) hipLaunchKernelGGL((attn_h16p_kernel<f16_tag, true>), pgrid, block, dyn, s, p);
+                    else hipLaunchKernelGGL((attn_h16p_kernel<f16_tag, false>), pgrid, block, dyn + tuning().attn_lds_pad, s, p);
+                }
+                break;
+            }
+            if (bf) {
+                if (bias) hipLaunchKernelGGL((attn_h16_kernel<bf16_tag, true>), grid, block, dyn, s, p);
+                else hipLaunchKernelGGL((attn_h16_kernel<bf16_tag, false>), grid, block, dyn + tuning().attn_lds_pad, s, p);
+            } else {
+                if (bias) hipLaunchKernelGGL((attn_h16_kernel<f16_tag, true>), grid, block, dyn, s, p);
+                else hipLaunchKernelGGL((attn_h16_kernel<f16_tag, false>), grid, block, dyn + tuning().attn_lds_pad, s, p);
+            }
             break;
-        case F16:
-            if (p.bias_table) hipLaunchKernelGGL((attn_h16_kernel<f16_tag, true>), grid, block, dyn, s, p);
-            else hipLaunchKernelGGL((attn_h16_kernel<f16_tag, false>), grid, block, dyn + tuning().attn_lds_pad, s, p);
-            break;
+        }
         case 3: {  // S3ENC_F32X3: fp32 q|k|v and output, split-precision products; all of its LDS is dynamic
             const size_t lds = (size_t)(4 * KBUF16 + 4 * VBUF16) * sizeof(u16) + dyn;
             hipError_t e = ensure_dynamic_lds<attn_x3_kernel>((int)lds);

@@ -45,6 +45,8 @@ struct Tuning {
                            // 240 costs +20 % (the tile rounds are tuned to 256 CUs: q|k|v's 756 tiles become four rounds) — keep 0
     int gemm16_rows = 1;   // gemm16.hip: 1 = GELU epilogues with a 16-bit output take the row-per-lane (no LDS) form, 0 = never
     int attn_lds_pad = 0;  // 16-bit attention occupancy probe
+    int attn_persist = 1;  // attention.hip, 16-bit modes: 1 = persistent workgroups that prefetch the next (batch, head, query block)
+                           // item's Q and first K / V tile under the current item's last tile (round 6; bit-identical), 0 = one-shot grid
     int conv0_nt = 1;      // frontend.hip, fp32 output: 1 = non-temporal row stores (the 2 GB activation streams past the caches:
                            // 0.578 -> 0.436 ms on HuBERT-base 32 x 10 s, round 4), 0 = plain stores
     int ws_inplace = 1;    // engine.hip, post-LN layers: 1 = LayerNorm 1 and fc2 work in place on ONE fp32 buffer (49 MB less

@@ -264,3 +264,94 @@ class DataParallelUpstream(torch.nn.Module):
         for i, h in enumerate(hidden):
             result[f"hidden_state_{i}"] = h
         return result
+
+
+class CopyComm:
+    """S3ENC_EXCHANGE_COPY of the C ABI (include/s3enc.h, csrc/comm.hip): the per-state exchange on the copy engines — every rank's
+    block is written into the peers' receive slabs by ``hipMemcpyAsync`` through IPC mappings, one stream per peer (all xGMI links
+    at once), each copy behind the encoder's "state l final" event, and no compute unit runs a collective's kernel beside the
+    encoder's GEMMs.  No RCCL: the ranks meet through ``torch.distributed`` of ANY backend (the 256-byte handles travel by
+    ``all_gather_object``), one PROCESS per GPU.  The receive slab is allocated once per (shape, dtype) and re-used by every
+    exchange — ``gather_layers`` returns it, and its contents are valid until the next exchange of that shape."""
+
+    def __init__(self, device: Optional[int] = None, group=None):
+        import ctypes as C
+
+        import torch.distributed as dist
+
+        from . import _lib
+
+        self._lib, self._C, self._group = _lib.load(), C, group
+        self.device = torch.cuda.current_device() if device is None else int(device)
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self._comms = {}  # (shape, dtype) -> (handle, slab): one registered slab per communicator
+
+    def _comm_for(self, shape, dtype):
+        C = self._C
+        from . import _lib
+
+        key = (tuple(shape), dtype)
+        if key in self._comms:
+            return self._comms[key]
+        import torch.distributed as dist
+
+        h = C.c_void_p()
+        _lib.check(self._lib.s3enc_comm_init_local(self.world, self.rank, self.device, C.byref(h)), "s3enc_comm_init_local")
+        NS, Bs = shape[0], shape[1]
+        slab = torch.empty((NS, self.world * Bs) + tuple(shape[2:]), dtype=dtype, device=torch.device("cuda", self.device))
+        if self.world > 1:
+            blob = C.create_string_buffer(_lib.COPY_HANDLE_BYTES)
+            _lib.check(self._lib.s3enc_comm_copy_export(h, C.c_void_p(slab.data_ptr()), slab.numel() * slab.element_size(), blob),
+                       "s3enc_comm_copy_export")
+            blobs = [None] * self.world
+            dist.all_gather_object(blobs, (tuple(shape), str(dtype), bytes(blob.raw)), group=self._group)
+            if any(b[:2] != (tuple(shape), str(dtype)) for b in blobs):
+                raise ValueError(f"CopyComm: slab shapes differ across ranks: {[b[:2] for b in blobs]}")
+            allb = C.create_string_buffer(b"".join(b[2] for b in blobs), _lib.COPY_HANDLE_BYTES * self.world)
+            _lib.check(self._lib.s3enc_comm_copy_attach(h, allb), "s3enc_comm_copy_attach")
+        self._comms[key] = (h, slab)
+        return h, slab
+
+    def gather_layers(self, hs: torch.Tensor, overlap_events: Optional[list] = None) -> torch.Tensor:
+        """(NS, Bs, T, D) on this rank -> the registered (NS, world * Bs, T, D) slab; asynchronous on the current stream."""
+        C = self._C
+        from . import _lib
+
+        NS = hs.shape[0]
+        per_state = hs[0].numel() * hs.element_size()
+        assert hs.is_cuda and hs[0].is_contiguous() and hs.stride(0) * hs.element_size() >= per_state
+        h, slab = self._comm_for(hs.shape, hs.dtype)
+        evs = None
+        if overlap_events is not None:
+            if len(overlap_events) < NS:
+                raise ValueError(f"{len(overlap_events)} overlap events for {NS} states")
+            evs = (C.c_void_p * NS)(*[int(ev.cuda_event) for ev in overlap_events[:NS]])
+        stream = torch.cuda.current_stream(hs.device).cuda_stream
+        _lib.check(self._lib.s3enc_comm_exchange_states(h, _lib.EXCHANGE_COPY, C.c_void_p(hs.data_ptr()), hs.stride(0) * hs.element_size(),
+                                                        C.c_void_p(slab.data_ptr()), slab.stride(0) * slab.element_size(), NS, per_state,
+                                                        evs, C.c_void_p(stream)), "s3enc_comm_exchange_states")
+        return slab
+
+    def status(self) -> int:
+        """0, or a bit mask of the peers a wait gave up on (deadline S3ENC_COPY_DEADLINE_MS); synchronises the exchange streams."""
+        C = self._C
+        from . import _lib
+
+        out = 0
+        for h, _ in self._comms.values():
+            st = C.c_int32()
+            _lib.check(self._lib.s3enc_comm_copy_status(h, C.byref(st)), "s3enc_comm_copy_status")
+            out |= st.value
+        return out
+
+    def close(self):
+        for h, _ in self._comms.values():
+            self._lib.s3enc_comm_destroy(h)
+        self._comms = {}
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -220,3 +220,82 @@ def test_all_pairs_exchange_executes_nccl_send_recv_on_one_gpu():
     finally:
         _lib.check(lib.s3enc_set_tuning(b"comm_self_p2p", 0))
         comm.close()
+
+
+def _worker_copy(rank, world, port, lengths, ret):
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ["S3ENC_COPY_DEADLINE_MS"] = "20000"   # (both ranks share one GPU and a cold start here: be generous, stay bounded)
+        import torch
+        import torch.distributed as dist
+
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from s3prl_amd.parallel import CopyComm, shard_bounds
+        from s3prl_amd.synth import named_config, synth_wavs, synth_weights
+        from s3prl_amd.upstream.hubert.expert import UpstreamExpert
+
+        cfg = named_config("tiny_hubert")
+        expert = UpstreamExpert.from_weights(cfg, synth_weights(cfg, 1))
+        wavs = [torch.from_numpy(w).cuda() for w in synth_wavs(lengths, 11)]
+        n_max = max(lengths)
+        beg, end, per = shard_bounds(len(wavs), world, rank)
+        mine = wavs[beg:end]
+        enc = expert._encoder_for(wavs[0].device)
+        events = enc.layer_events()
+        comm = CopyComm()
+        outs = []
+        for step in range(4):  # repeated exchanges into the SAME slab: the ack protocol must keep step i + 1 out of step i's readers
+            scale = 1.0 + step
+            hs = expert.encode([w * scale for w in mine], n_max=n_max)
+            got = comm.gather_layers(hs, overlap_events=events)
+            outs.append(got.clone())  # (stream-ordered behind the exchange; the slab is overwritten by the next step)
+        hs16 = expert.encode(mine, n_max=n_max).half()  # a second slab shape / dtype: its own registration
+        got16 = comm.gather_layers(hs16).clone()
+        torch.cuda.synchronize()
+        assert comm.status() == 0, f"a wait of the copy exchange timed out: {comm.status():#x}"
+        full = [expert.encode([w * (1.0 + step) for w in wavs]) for step in range(4)]
+        torch.cuda.synchronize()
+        ok = all(torch.equal(o, f) for o, f in zip(outs, full)) and torch.equal(got16, full[0].half())
+        ret.put(("rank", rank, bool(ok), [float(o.double().abs().sum()) for o in outs]))
+        dist.barrier()
+        comm.close()
+        dist.destroy_process_group()
+    except Exception:
+        import traceback
+
+        ret.put(("error", traceback.format_exc()))
+        os._exit(1)
+
+
+def test_copy_engine_exchange_two_processes_one_gpu():
+    """S3ENC_EXCHANGE_COPY (round 6; include/s3enc.h): two PROCESSES on this box's single GPU map each other's receive slab and
+    mailbox through hipIpcGetMemHandle / hipIpcOpenMemHandle and push their shard's states with one hipMemcpyAsync per state and
+    peer, behind the encoder's layer events.  Layout (rank r's block at [l][r]), ordering (four back-to-back exchanges into one
+    slab; a second slab of another dtype) and the deadline word are checked against the single-process full-batch result, bit for
+    bit, on both ranks.  On a real node the same code moves the blocks over xGMI on the SDMA engines."""
+    import torch.multiprocessing as mp
+
+    lengths = [4000, 2345, 3111, 800]
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = 34500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker_copy, args=(r, 2, port, lengths, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = []
+    for _ in range(2):
+        item = ret.get(timeout=150)
+        if item[0] == "error":
+            for p in procs:
+                p.kill()
+            pytest.fail(item[1])
+        got.append(item)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(g[1] for g in got) == [0, 1] and all(g[2] for g in got), got
+    assert got[0][3] == got[1][3]   # both ranks hold the same gathered states

@@ -37,6 +37,9 @@ for n in $ns; do
   [ $n -eq $maxn ] || continue
   # at the full node only: the exchange behind the C ABI (what a non-Python binder runs), the featurized form (13x fewer bytes), none
   run weak_fp16x2_n${n}_direct_cabi $n --dtype fp16x2 --steps 100 --warmup 5 --exchange-algo direct --exchange-via cabi
+  # round 6: the copy-engine form (S3ENC_EXCHANGE_COPY: IPC-mapped slabs, one hipMemcpyAsync per state and peer, no CU, no RCCL)
+  run weak_fp16x2_n${n}_copy $n --dtype fp16x2 --steps 100 --warmup 5 --exchange-algo copy
+  run weak_fp32_n${n}_copy $n --dtype fp32 --steps 40 --warmup 5 --exchange-algo copy
   run weak_fp16x2_n${n}_featurized $n --dtype fp16x2 --steps 100 --warmup 5 --gather featurized
   run weak_fp16x2_n${n}_none $n --dtype fp16x2 --steps 100 --warmup 5 --gather none
   # the CU side of the exchange against its one-GPU proxy (profiles/r05_cu_contention.md: +2 % for foreign workgroups, +20 % for a
