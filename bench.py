@@ -358,6 +358,8 @@ def main():
                 if exchange:
                     gather_layers(feat.unsqueeze(0), out=gathered.unsqueeze(0), algo=args.exchange_algo)
                 return feat
+            if copyc is not None and exchange:
+                copyc.release()  # nothing reads the gathered slab of the previous step: the peers may write while this forward runs
             hs = expert.encode(wavs, n_max=n, out_dtype=args.dtype if gather == "layers16" else None)
             if exchange and gather != "none":
                 # one all-gather per layer (hidden_states[l] stays a contiguous (B_global, T, D) block), issued on a

@@ -227,6 +227,9 @@ int s3enc_comm_init_local(int32_t world, int32_t rank, int32_t device, s3enc_com
 int s3enc_comm_copy_export(s3enc_comm c, void* recv_slab, int64_t bytes, void* handle_out);
 int s3enc_comm_copy_attach(s3enc_comm c, const void* handles /* world x S3ENC_COPY_HANDLE_BYTES, in rank order */);
 int s3enc_comm_copy_status(s3enc_comm c, int32_t* status);
+/* optional: marks, on `stream`, the point behind which nobody reads the slab's current contents any more — call it before enqueueing
+ * the next forward, and that forward's per-state pushes overlap it (without it the next exchange counts from its own call) */
+int s3enc_comm_copy_release(s3enc_comm c, void* stream);
 int s3enc_comm_exchange_states(s3enc_comm c, int32_t algo, const void* send, int64_t send_state_stride, void* recv,
                                int64_t recv_state_stride, int32_t n_states, int64_t bytes_per_state, void* const* ready_events,
                                void* stream);
@@ -287,9 +290,12 @@ int s3enc_debug_clock_sample(uint64_t* out3_device, void* stream);
  *                   widening needs a new handle);
  *   "comm_self_p2p": S3ENC_EXCHANGE_DIRECT test hook: 1 = a rank's own block travels as an ncclSend-to-self / ncclRecv-from-self pair
  *                   inside the state's group instead of a device copy (how the all-pairs code executes on a one-GPU box); default 0;
- *   "attn_persist": 16-bit modes: 1 (default) = the attention kernel runs as persistent workgroups that fetch the next (batch, head,
- *                   query block) item's operands under the current item's last key tile, 0 = the one-shot grid of rounds 1-5; results
- *                   are bit-identical;
+ *   "fp16x2_conv1_f32": S3ENC_F16X2, read at s3enc_create: 1 = conv0 writes fp32 activations and conv1 reads them through the three-term
+ *                   GEMM like conv2.. already do (removes the mode's last fp16 rounding inside the conv stack: the worst weight seed of
+ *                   profiles/r06_parity_seeds.md moves from 8.3e-4 to ~7e-4, for conv1 at the three-term rate); default 0;
+ *   "attn_persist": 1 = the attention kernels run as persistent workgroups that fetch the next (batch, head, query block) item's
+ *                   operands under the current item's last key tile, 0 (default) = the one-shot grid; bit-identical results; a measured
+ *                   prototype that lost (profiles/r06_attention_persist.md), kept for re-measurement;
  *   "reserve_cus":  CUs the persistent one-workgroup-per-CU GEMM of the 16-bit modes leaves out of its grid (default 0; a measurement
  *                   knob — leaving CUs to a collective's channel kernels costs more than sharing them: profiles/r05_cu_contention.md);
  *   "conv0_nt":     1 (default) = the fp32 conv0 kernel writes its activation with non-temporal stores, 0 = plain stores;

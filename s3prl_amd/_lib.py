@@ -94,6 +94,7 @@ _PROTOS = {
     "s3enc_comm_copy_export": (C.c_int, [_VP, _VP, _I64, _VP]),
     "s3enc_comm_copy_attach": (C.c_int, [_VP, _VP]),
     "s3enc_comm_copy_status": (C.c_int, [_VP, C.POINTER(_I32)]),
+    "s3enc_comm_copy_release": (C.c_int, [_VP, _VP]),
     "s3enc_set_handle_tuning": (C.c_int, [_VP, C.c_char_p, _I32]),
     "s3enc_set_tuning": (C.c_int, [C.c_char_p, _I32]),
     "s3enc_op_gemm": (C.c_int, [_I32, _VP, _I64, _I64, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _VP, _VP, _VP, _VP,

@@ -458,12 +458,48 @@ template <> struct Mma16<f16_tag> {
     }
 };
 
+// The softmax reference -m as the initial value of a score block's accumulator.  Vector form: 16 registers that only change when
+// the reference moves (the MFMA takes them as its C operand directly).  Scalar form (round 6): ONE register, the 16-register block is
+// filled from it per 32-key half (16 v_mov) — the bias-free kernel drops from 168 registers + 5 spilled to 144 and no spill, and its
+// compiler-made schedule gets 7-10 % faster (attn_lab: 62.4 -> 58.0 us HuBERT-base, 81.0 -> 73.1 HuBERT-large, 150 -> 139 WavLM-large
+// without bias; profiles/r06_attn_lab.md).  The bias kernel (two waves per SIMD, registers to spare) keeps the vector: there the
+// extra moves only cost (154 -> 168 us).  Same values either way: bit-identical.
+template <bool SCALAR> struct RefM;
+template <> struct RefM<false> {
+    f32x16 v;
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = 0.f;
+    }
+    __device__ __forceinline__ f32x16 block() const { return v; }
+    __device__ __forceinline__ void lower(float d) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] -= d;
+    }
+};
+template <> struct RefM<true> {
+    float s;
+    __device__ __forceinline__ void zero() { s = 0.f; }
+    __device__ __forceinline__ f32x16 block() const {
+        f32x16 x;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[r] = s;
+        return x;
+    }
+    __device__ __forceinline__ void lower(float d) { s -= d; }
+};
+#ifndef S3_ATTN_EXP
+#define S3_ATTN_EXP 0  // lab switch (tools/micro/build.sh): 4 = the bias kernel with the scalar reference at three waves per SIMD
+#endif
+constexpr bool attn_ref_scalar(bool bias) { return !bias || (S3_ATTN_EXP & 4); }
+constexpr int attn_h16_waves(bool bias) { return (bias && !(S3_ATTN_EXP & 4)) ? 2 : 3; }
+
 // BIAS: the WavLM relative-position bias path compiled in (its 16 table reads in flight need > 168 registers: two waves per
 // SIMD); the bias-free variant fits 152 registers = 3 waves per SIMD.
 // Operand contract of the 16-bit kernels: q arrives pre-scaled by head_dim^-0.5 * log2(e) (folded into W_q / b_q at pack
 // time), so the scores are base-2 logarithms and the softmax is exp2 without a per-score multiply.
 template <typename T, bool BIAS>
-__global__ __launch_bounds__(256, BIAS ? 2 : 3) void attn_h16_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, attn_h16_waves(BIAS)) void attn_h16_kernel(AttnParams p) {
     __shared__ __attribute__((aligned(16))) u16 Ks[2 * KBUF16];
     __shared__ __attribute__((aligned(16))) u16 Vt[2 * VBUF16];
     const AttnWork wk = attn_work(p);
@@ -511,9 +547,11 @@ __global__ __launch_bounds__(256, BIAS ? 2 : 3) void attn_h16_kernel(AttnParams 
     //     and the last (partial) tile is peeled, so the steady-state body has no mask / half-count branches;
     //   * one 32-key score tile is live at a time: with both halves' chains in flight (and their K / V fragments
     //     pre-loaded) the kernel needs 216 registers = two waves per SIMD, and was slower than this form at three.
-    f32x16 o0, o1, negm;
+    f32x16 o0, o1;
+    RefM<attn_ref_scalar(BIAS)> negm;
+    negm.zero();
 #pragma unroll
-    for (int r = 0; r < 16; ++r) o0[r] = o1[r] = negm[r] = 0.f;
+    for (int r = 0; r < 16; ++r) o0[r] = o1[r] = 0.f;
     float l_run = 0.f;
     bool first = true;
     const float gate2 = gate * 1.44269504088896340736f;  // the bias joins log2-domain scores
@@ -568,7 +606,7 @@ __global__ __launch_bounds__(256, BIAS ? 2 : 3) void attn_h16_kernel(AttnParams 
         const u16* vt = vf_rd + (kt & 1) * VBUF16;
         const bool two = FULL || kt * KT16 + 32 < valid;  // wave-uniform: the second half has at least one valid key
         auto scores = [&](int h) {
-            f32x16 sc = negm;
+            f32x16 sc = negm.block();
             if (S3_PROBE(p, 8)) return sc;
 #pragma unroll
             for (int st = 0; st < 4; ++st) {
@@ -607,8 +645,8 @@ __global__ __launch_bounds__(256, BIAS ? 2 : 3) void attn_h16_kernel(AttnParams 
                     o0[r] *= alpha;
                     o1[r] *= alpha;
                     sc[r] -= delta;
-                    negm[r] -= delta;
                 }
+                negm.lower(delta);
                 l_run *= alpha;
                 first = false;
             }
@@ -709,7 +747,7 @@ __global__ __launch_bounds__(256, BIAS ? 2 : 3) void attn_h16_kernel(AttnParams 
 // query blocks of a unit adjacent) round-robin, so the co-resident workgroups of an XCD work on the same few units and K / V
 // come from HBM once.
 template <typename T, bool BIAS>
-__global__ __launch_bounds__(256, BIAS ? 2 : 3) void attn_h16p_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, attn_h16_waves(BIAS)) void attn_h16p_kernel(AttnParams p) {
     __shared__ __attribute__((aligned(16))) u16 Ks[2 * KBUF16];
     __shared__ __attribute__((aligned(16))) u16 Vt[2 * VBUF16];
     extern __shared__ float bias_s[];
@@ -814,12 +852,14 @@ __global__ __launch_bounds__(256, BIAS ? 2 : 3) void attn_h16p_kernel(AttnParams
     __syncthreads();
     int buf = 0;  // the LDS buffer the next tile to multiply sits in (runs on across items)
 
-    f32x16 o0, o1, negm;
+    f32x16 o0, o1;
+    RefM<attn_ref_scalar(BIAS)> negm;
     float l_run;
     bool first;
     while (true) {
+        negm.zero();
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o0[r] = o1[r] = negm[r] = 0.f;
+        for (int r = 0; r < 16; ++r) o0[r] = o1[r] = 0.f;
         l_run = 0.f;
         first = true;
 
@@ -830,7 +870,7 @@ __global__ __launch_bounds__(256, BIAS ? 2 : 3) void attn_h16p_kernel(AttnParams
             const u16* vt = vf_rd + buf * VBUF16;
             const bool two = FULL || kt * KT16 + 32 < valid;  // wave-uniform: the second half has at least one valid key
             auto scores = [&](int h) {
-                f32x16 sc = negm;
+                f32x16 sc = negm.block();
                 if (S3_PROBE(p, 8)) return sc;
 #pragma unroll
                 for (int st = 0; st < 4; ++st) {
@@ -864,8 +904,8 @@ __global__ __launch_bounds__(256, BIAS ? 2 : 3) void attn_h16p_kernel(AttnParams
                         o0[r] *= alpha;
                         o1[r] *= alpha;
                         sc[r] -= delta;
-                        negm[r] -= delta;
                     }
+                    negm.lower(delta);
                     l_run *= alpha;
                     first = false;
                 }
@@ -1220,7 +1260,7 @@ hipError_t launch_attention(int dtype, const AttnParams& p, hipStream_t s) {
             if (tuning().attn_persist) {
                 // persistent workgroups: 3 (BIAS: 2) per CU — what __launch_bounds__ guarantees registers for — but never more
                 // than the XCD's share of items needs (a grid of idle workgroups is not free)
-                const int per_cu = bias ? 2 : 3;
+                const int per_cu = attn_h16_waves(bias);
                 const long items8 = (long)units8 * ((p.T + QT - 1) / QT);  // items of the fullest XCD
                 const long wpx = std::min<long>(items8, 32L * per_cu);     // 32 CUs per XCD
                 dim3 pgrid((unsigned)(8 * wpx));

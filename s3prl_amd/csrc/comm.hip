@@ -115,6 +115,8 @@ struct s3enc_comm_s {
     int64_t slab_bytes = 0;
     uint64_t seq = 0;
     bool attached = false;
+    hipEvent_t free_ev = nullptr;  // s3enc_comm_copy_release: "the slab's last readers are in front of this point of the caller's stream"
+    bool have_free = false;
     std::vector<CopyPeer> peers;
 };
 
@@ -174,15 +176,22 @@ static int copy_exchange(s3enc_comm c, const void* send, int64_t send_state_stri
     hipStream_t caller = (hipStream_t)stream;
     const uint64_t q = ++c->seq;
     const long long ticks = copy_deadline_ticks(c->device);
-    // everything the caller enqueued so far — the consumers of the slab's previous contents, the producers of `send` when there are
-    // no per-state events — is in front of the acks and of the first push
+    // Two gates.  `slab_free`: the last readers of the slab's previous contents — in front of the acks and of my own block's copy.
+    // With s3enc_comm_copy_release the caller marked that point BEFORE it enqueued this step's forward, so the pushes of state l can
+    // start behind "state l final" while the later layers still compute; without it the point is "now" (the whole forward the caller
+    // enqueued before this call is in front of the exchange: correct, nothing overlaps).  `here`: everything enqueued so far — what the
+    // pushes wait for when there are no per-state events.
     HIP_TRY(hipEventRecord(c->done, caller));
-    HIP_TRY(hipStreamWaitEvent(c->stream, c->done, 0));
+    hipEvent_t here = c->done, slab_free = c->have_free ? c->free_ev : c->done;
+    c->have_free = false;
+    HIP_TRY(hipStreamWaitEvent(c->stream, slab_free, 0));
+    if (!ready_events) HIP_TRY(hipStreamWaitEvent(c->stream, here, 0));
     uint64_t* err = c->mbox ? c->mbox + 2 * c->world : nullptr;
     for (int pi = 0; pi < c->world; ++pi) {
         if (pi == c->rank) continue;
         CopyPeer& pr = c->peers[pi];
-        HIP_TRY(hipStreamWaitEvent(pr.stream, c->done, 0));
+        HIP_TRY(hipStreamWaitEvent(pr.stream, slab_free, 0));
+        if (!ready_events) HIP_TRY(hipStreamWaitEvent(pr.stream, here, 0));
         hipLaunchKernelGGL(copy_put_kernel, dim3(1), dim3(1), 0, pr.stream, pr.mbox + c->world + c->rank, q);  // ack: p may write exchange q here
         // ... and p must have said the same to me before my first block goes into ITS slab
         hipLaunchKernelGGL(copy_wait_kernel, dim3(1), dim3(64), 0, pr.stream, (const uint64_t*)(c->mbox + c->world), c->world, -1, pi, q, err, ticks);
@@ -303,6 +312,18 @@ int s3enc_comm_copy_attach(s3enc_comm c, const void* handles) {
     return 0;
 }
 
+// "Every reader of the receive slab's current contents has been enqueued on `stream`": call it BEFORE enqueueing the forward whose
+// states the next S3ENC_EXCHANGE_COPY exchange moves — that exchange then tells the peers "you may write" at this point of the stream
+// instead of at the point of its own call, i.e. the pushes behind the layer events overlap the forward.  Optional (see copy_exchange).
+int s3enc_comm_copy_release(s3enc_comm c, void* stream) {
+    if (!c) return fail("s3enc_comm_copy_release: null argument");
+    DeviceGuard dg(c->device);
+    if (!c->free_ev) HIP_TRY(hipEventCreateWithFlags(&c->free_ev, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(c->free_ev, (hipStream_t)stream));
+    c->have_free = true;
+    return 0;
+}
+
 // 0 = every wait of every S3ENC_EXCHANGE_COPY exchange so far met its deadline; else bit p = a wait for rank p (mod 32) timed out
 // (S3ENC_COPY_DEADLINE_MS, default 5000) — the slab's contents are then not valid.  Synchronises the communicator's streams.
 int s3enc_comm_copy_status(s3enc_comm c, int32_t* status) {
@@ -381,6 +402,7 @@ int s3enc_comm_destroy(s3enc_comm c) {
         if (pr.mbox_map) (void)hipIpcCloseMemHandle(pr.mbox_map);
     }
     if (c->mbox) (void)hipFree(c->mbox);
+    if (c->free_ev) (void)hipEventDestroy(c->free_ev);
     if (c->done) (void)hipEventDestroy(c->done);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;

@@ -106,51 +106,30 @@ __global__ __launch_bounds__(256) void posconv_kernel(PosConvParams p) {
         for (int n = 0; n < NT; ++n) acc[f][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const float* xrow = xs + (wave * (16 * PC_FT) + l15) * RS + 4 * kk;  // frame tile f: + 16 f rows
-    // Round 6: the fragment reads of a tap are software-pipelined.  Before, every group of 2 x 4 MFMAs sat behind its own
-    // `ds_read_b128 -> s_waitcnt lgkmcnt(0)` (the weight fragment of (chunk, channel tile) was read right where it was used): a wave
-    // waited an LDS round trip every 256 matrix cycles and only the CU's other workgroup filled the gap (mfma_busy 0.84).  Now the A
-    // fragments of the NEXT tap — the same window one row further down, no barrier in the way — are read while this tap multiplies,
-    // the weight fragments of a tap go out in one burst behind the tap's barrier and are waited for one by one (counted lgkmcnt), and
-    // the next tap's weights are written to their LDS buffer in the MIDDLE of the tap (the global loads issued at its start have
-    // landed by then) instead of in front of the barrier.  Same MFMA sequence per accumulator: bit-identical.
-    float4 a_cur[PC_FT][NCC], a_nxt[PC_FT][NCC];
-    auto read_a = [&](float4 (&a)[PC_FT][NCC], int j) {
-        const float* xa = xrow + j * RS;
-#pragma unroll
-        for (int cc = 0; cc < NCC; ++cc)
-#pragma unroll
-            for (int f = 0; f < PC_FT; ++f) a[f][cc] = *(const float4*)(xa + f * 16 * RS + 16 * cc);
-    };
-    read_a(a_cur, 0);
     for (int j = 0; j < K; ++j) {
         if (j + 1 < K) wload(j + 1);
         const float* wb = wl + (j & 1) * WSZ + l15 * 16 + 4 * (kk ^ pc_w_swizzle(l15));  // (the pack stored slot kk there)
-        float4 w[NCC][NT];
-#pragma unroll
-        for (int cc = 0; cc < NCC; ++cc)
-#pragma unroll
-            for (int n = 0; n < NT; ++n) w[cc][n] = *(const float4*)(wb + (cc * DG + n * 16) * 16);
-        if (j + 1 < K) read_a(a_nxt, j + 1);
+        const float* xa = xrow + j * RS;
 #pragma unroll
         for (int cc = 0; cc < NCC; ++cc) {
+            float4 a[PC_FT];
+#pragma unroll
+            for (int f = 0; f < PC_FT; ++f) a[f] = *(const float4*)(xa + f * 16 * RS + 16 * cc);
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
+                const float4 w = *(const float4*)(wb + (cc * DG + n * 16) * 16);
                 // per accumulator the k order is x, y, z, w of chunk cc, chunks and taps ascending — as before: a frame's
                 // result does not depend on the frame tile it sits in
 #pragma unroll
                 for (int f = 0; f < PC_FT; ++f) {
-                    acc[f][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[f][cc].x, w[cc][n].x, acc[f][n], 0, 0, 0);
-                    acc[f][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[f][cc].y, w[cc][n].y, acc[f][n], 0, 0, 0);
-                    acc[f][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[f][cc].z, w[cc][n].z, acc[f][n], 0, 0, 0);
-                    acc[f][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[f][cc].w, w[cc][n].w, acc[f][n], 0, 0, 0);
+                    acc[f][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[f].x, w.x, acc[f][n], 0, 0, 0);
+                    acc[f][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[f].y, w.y, acc[f][n], 0, 0, 0);
+                    acc[f][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[f].z, w.z, acc[f][n], 0, 0, 0);
+                    acc[f][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[f].w, w.w, acc[f][n], 0, 0, 0);
                 }
             }
-            if (cc == NCC / 2 && j + 1 < K) wstore((j + 1) & 1);  // (buffer (j + 1) & 1 was last read in tap j - 1: every wave is past that barrier)
         }
-#pragma unroll
-        for (int cc = 0; cc < NCC; ++cc)
-#pragma unroll
-            for (int f = 0; f < PC_FT; ++f) a_cur[f][cc] = a_nxt[f][cc];
+        if (j + 1 < K) wstore((j + 1) & 1);
         __syncthreads();
     }
 

@@ -333,6 +333,16 @@ class CopyComm:
                                                         evs, C.c_void_p(stream)), "s3enc_comm_exchange_states")
         return slab
 
+    def release(self) -> None:
+        """Call BEFORE enqueueing a forward whose states the next ``gather_layers`` moves: "whoever reads the slabs' current
+        contents has been enqueued on the current stream" — the peers may then overwrite them while that forward still computes
+        (the per-state pushes overlap it).  Without it an exchange counts from its own call: correct, not overlapped."""
+        stream = torch.cuda.current_stream(torch.device("cuda", self.device)).cuda_stream
+        from . import _lib
+
+        for h, _ in self._comms.values():
+            _lib.check(self._lib.s3enc_comm_copy_release(h, self._C.c_void_p(stream)), "s3enc_comm_copy_release")
+
     def status(self) -> int:
         """0, or a bit mask of the peers a wait gave up on (deadline S3ENC_COPY_DEADLINE_MS); synchronises the exchange streams."""
         C = self._C

@@ -211,6 +211,7 @@ def test_all_pairs_exchange_executes_nccl_send_recv_on_one_gpu():
                     flat = torch.full((hs.shape[0], 2 * hs[0].numel() + 5), float("nan"), device="cuda")
                     view = flat.as_strided(hs.shape, (flat.stride(0),) + tuple(hs[0].stride()))
                 flat.fill_(float("nan"))
+                torch.cuda.synchronize()  # (with layer events the exchange of state l waits for event l only, not for the fill above)
                 comm.gather_layers(hs, overlap_events=events, out=view, algo="direct")
                 torch.cuda.synchronize()
                 assert torch.equal(view, hs) and torch.isnan(flat[:, hs[0].numel():]).all()
@@ -250,6 +251,8 @@ def _worker_copy(rank, world, port, lengths, ret):
         outs = []
         for step in range(4):  # repeated exchanges into the SAME slab: the ack protocol must keep step i + 1 out of step i's readers
             scale = 1.0 + step
+            if step >= 2:
+                comm.release()  # (steps 2, 3: the overlapped form — the clone below, the slab's only reader, is already enqueued)
             hs = expert.encode([w * scale for w in mine], n_max=n_max)
             got = comm.gather_layers(hs, overlap_events=events)
             outs.append(got.clone())  # (stream-ordered behind the exchange; the slab is overwritten by the next step)
