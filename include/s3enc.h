@@ -50,12 +50,22 @@ enum { S3ENC_F32 = 0, S3ENC_BF16 = 1, S3ENC_F16 = 2,
         * 3/16 of the exact-fp32 matrix cost.  Opt-in; S3ENC_F32 stays the exact default. */
        S3ENC_F32X3 = 3,
        /* fp16 data flow (exactly S3ENC_F16: fp16 activations / attention, fp32 accumulate, norms, softmax, residual) with
-        * every GEMM weight kept as TWO fp16 terms (w = hi + lo) and the contraction run over both: the weights' rounding
-        * error disappears, leaving the activations'.  Where a rounded fp16 OPERAND carries the error budget (conv2.. of a
-        * GroupNorm extractor, post_extract_proj, out_proj) the GEMM reads fp32 activations through the three-term kernel.
-        * Measured on the reference's goldens: 3.7e-4 ... 8.3e-4 relative error on the hidden states,
-        * <= 7.2e-4 on every HuBERT / wav2vec 2.0 / WavLM fixture incl. released-checkpoint statistics, where S3ENC_F16 is
-        * 0.9e-3 ... 2.8e-3 — inside the path's 1e-3 tolerance at 2.7x the S3ENC_F32 throughput.  Opt-in. */
+        * every GEMM weight kept as TWO terms (w = hi + lo) and the contraction run over both: the weights' rounding error
+        * disappears, leaving the activations'.  What a binder gets BY DEFAULT:
+        *   - hi = fp16(w); lo = a second fp16 term — or, for q|k|v, fc1 and fc2 where the weight's shape pays for it, an MX-fp4
+        *     image of lo (per row and 32 k an E8M0 scale + 32 e2m1 values, packed at s3enc_create) multiplied on the scaled-MFMA
+        *     pipe in the same K step: 4.8e-5 of weight error per GEMM instead of 5e-7.  Tuning key "gemm16_mx" (read at
+        *     s3enc_create, default 14; 0 = two fp16 terms everywhere) selects the GEMMs;
+        *   - where a rounded fp16 OPERAND carries the error budget the GEMM reads fp32 activations through the three-term
+        *     kernel instead: conv2.. of EVERY extractor (GroupNorm and layer-norm: conv1 writes fp32), post_extract_proj (the
+        *     fp32 LayerNorm(C) output) and out_proj (the attention kernel writes fp32).  "fp16x2_conv1_f32" = 1 adds conv1.
+        * Measured on outputs of the reference itself (profiles/r06_parity_seeds.md, 39 full-dimension fixtures on
+        * released-checkpoint-like weight statistics, weight seeds 0-6 x five models): max relative error of a hidden state
+        * 2.5e-4 ... 8.6e-4, median 5.3e-4 (8.0e-4 worst with conv1 on fp32 rows) — inside the path's 1e-3 on every seed, where
+        * S3ENC_F16 is 0.9e-3 ... 2.8e-3 and S3ENC_BF16 0.7e-2 ... 1.5e-2 — at 3.1x the S3ENC_F32 throughput on HuBERT-base.
+        * Its stated limit: an FFN whose hidden activation leaves the fp16 range (GELU(fc1) > 65504: fc1 scaled x1000+ on the
+        * pretrained-like models, profiles/r05_fp16_cliff.md) returns non-finite states — reported by s3enc_forward_status; with
+        * fc1 x10 ... x1000 WavLM-large settles at 1.2-1.4e-3.  Opt-in. */
        S3ENC_F16X2 = 4 };
 
 /* Hyper-parameters that select kernel variants.

@@ -349,6 +349,46 @@ def test_attention(dtype, T, rel):
     assert err < {"fp32": 2e-5, "bf16": 1.5e-2, "fp16": 2e-3, "fp32x3": 5e-5}[dtype], f"attention {dtype} T={T}: rel-err {err:.3e}"
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
+@pytest.mark.parametrize("T,rel", [(37, False), (499, False), (300, 40), (749, 800)])
+def test_persistent_attention_is_bit_identical_to_the_one_shot_grid(dtype, T, rel):
+    """Round 6, tuning key `attn_persist` (default 0: a measured prototype that lost, profiles/r06_attention_persist.md): persistent
+    workgroups walk the (batch, head, query block) items and fetch the next item's operands through a buffer descriptor (rows past
+    the last frame read as zero instead of re-reading it) — every product and every softmax update in the same order, so the
+    result must equal the one-shot grid's bit for bit, ragged batches, an utterance of ONE valid frame and the WavLM bias included."""
+    torch = _torch()
+    from s3prl_amd import _lib
+
+    lib = _lib.load()
+    rng = np.random.default_rng(T + 1)
+    B, H = 5, 3  # 15 (batch, head) units over 8 XCDs: uneven item lists, some workgroups walk several items
+    D = 64 * H
+    qkv = rng.standard_normal((B * T, 3 * D)).astype(np.float32)
+    qkv[:, :D] *= 0.35
+    qkv[T // 2, D:2 * D] *= 4.0
+    valid = np.array([T, max(1, T // 3), max(1, T - 7), 1, max(1, T - 64)], dtype=np.int32)
+    table = gate = None
+    if rel:
+        table = rng.standard_normal((H, 2 * rel + 1)).astype(np.float32)
+        gate = (1 + rng.random((B, H, T))).astype(np.float32)
+    dq = _dev(qkv, dtype)
+    dvalid = torch.from_numpy(valid).cuda()
+    dtable = _dev(table) if rel else None
+    dgate = _dev(gate) if rel else None
+    outs = []
+    try:
+        for persist in (0, 1):
+            _lib.check(lib.s3enc_set_tuning(b"attn_persist", persist))
+            out = torch.full((B * T, D), float("nan"), device="cuda", dtype=dq.dtype)
+            _lib.check(lib.s3enc_op_attention(_lib.DTYPES[dtype], _ptr(dq), _ptr(out), _ptr(dvalid), B, T, H, _ptr(dtable), int(rel),
+                                              _ptr(dgate), None), "s3enc_op_attention")
+            torch.cuda.synchronize()
+            outs.append(out.view(torch.int16 if dq.dtype != torch.float32 else torch.int32).cpu().numpy())
+    finally:
+        _lib.check(lib.s3enc_set_tuning(b"attn_persist", 0))
+    assert np.array_equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16", "fp32x3"])
 def test_attention_with_every_score_far_below_zero(dtype):
     """q . b_k shifts all scores of a query by the same amount — softmax-invariant, so nothing in training bounds it.  With

@@ -14,12 +14,18 @@ REL_TOL = 1e-4
 
 def _cpu_oracle_cases():
     """Every fixture but the bulk of round 6's weight-seed sweep: the sweep exists for the GPU modes (tests/test_encoder_gpu.py runs
-    all 32 of its fixtures); the oracles are pinned by seed 1 of each of its five models and by the 56 fixtures of earlier rounds —
-    the other 27 would add a quarter of an hour of CPU time and no new code path."""
-    return [n for n in golden_names() if not golden_meta(n).get("seed_sweep") or (n.endswith("_s1_pl") and "15s" not in n)]
+    all 32 of its fixtures); the oracles are pinned by seed 1 of its three base models and by the 56 fixtures of earlier rounds (which
+    hold both large models at three shapes each) — the other 29 would add a quarter of an hour of CPU time and no new code path."""
+    keep = {"hubert_base_s1_pl", "wav2vec2_base_s1_pl", "data2vec_base_s1_pl"}  # (the large models: `*_large_pl`, `*_large_10s*`, `*_15s_*` of rounds 2-5)
+    return [n for n in golden_names() if not golden_meta(n).get("seed_sweep") or n in keep]
 
 
-@pytest.mark.parametrize("name", _cpu_oracle_cases())
+# the numpy restatement is O(minutes) on the full-size batches: one full-size fixture per large model stays (hubert_large_10s,
+# wavlm_large_15s_pad); their pretrained-like twins are pinned through the torch restatement below (same fixtures, a tenth of the time)
+_NUMPY_SKIP = {"hubert_large_10s_pl", "wavlm_large_15s_pl"}
+
+
+@pytest.mark.parametrize("name", [n for n in _cpu_oracle_cases() if n not in _NUMPY_SKIP])
 def test_oracle_matches_reference_golden(name, golden_loader):
     meta, cfg, weights, wavs, golden, norms = golden_loader(name)
     hs = O.forward(cfg, weights, wavs, dtype=np.float32, selection=meta.get("selection"))
