@@ -166,6 +166,17 @@ __global__ __launch_bounds__(128 * WN, WPE) void gemm16_big_kernel(GemmParams p)
             tile_step = 1;
         }
     }
+#if defined(S3_GEMM_PROBE) && defined(__HIP_DEVICE_COMPILE__)
+    // lab only (tools/micro/gemm16_lab `cmp ... <skew>0007`): every second workgroup of an XCD starts (variant >> 8) x 2 us late — what
+    // would it buy if the workgroups' epilogue bursts did NOT land in the same microsecond (the premise of a skewed / stream-K walk)?
+    if constexpr (PERSIST) {
+        const int sk = (p.variant >> 8) & 0xff;
+        if (sk && ((blockIdx.x >> 3) & 1)) {
+            const long long t0 = wall_clock64();
+            while (wall_clock64() - t0 < sk * 200LL) __builtin_amdgcn_s_sleep(8);
+        }
+    }
+#endif
     int m0, n0, b;  // the tile being multiplied / written
     auto coords = [&](int t, int& cm0, int& cn0, int& cb) {
         const int tn = t % n_tiles;

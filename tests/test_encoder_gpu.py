@@ -439,8 +439,21 @@ def test_fp32x3_on_pretrained_like_statistics(name, golden_loader):
 PL_16BIT_TOL = {"fp16x2": 7.5e-4, "fp16": 4e-3, "bf16": 3e-2}  # fp16x2: round 5 (6.6e-4 worst: profiles/r05_parity.md)
 
 
-@pytest.mark.parametrize("dtype", ["fp16x2", "fp16", "bf16"])
-@pytest.mark.parametrize("name", PRETRAINED_LIKE)
+def _pl_16bit_cases():
+    """fp16x2 on EVERY pretrained-like fixture (the seed sweep included: that is what the sweep is for); the one-term modes fp16 / bf16
+    — reported, not claimed to meet the tolerance — on the fixtures of rounds 4-5 and on seeds 1-2 of the sweep (the lease's time)."""
+    from conftest import golden_meta
+
+    out = []
+    for n in PRETRAINED_LIKE:
+        sweep = golden_meta(n).get("seed_sweep")
+        for d in ("fp16x2", "fp16", "bf16"):
+            if d == "fp16x2" or not sweep or "_s1_" in n or "_s2_" in n:
+                out.append((n, d))
+    return out
+
+
+@pytest.mark.parametrize("name,dtype", _pl_16bit_cases())
 def test_16bit_modes_on_pretrained_like_statistics(name, dtype, golden_loader):
     """Outlier channels of a few hundred, LayerNorm gains and int16-scale PCM must neither overflow the fp16 range nor
     produce a NaN anywhere, and each mode stays inside its own bound."""

@@ -84,6 +84,8 @@ static int compare(int argc, char** argv) {
             for (int c = 0; c < nm; ++c) {
                 s3::g_tuning.gemm16_big = modes[c] % 100;  // (column 107 = mode 7 with gemm16_pp = 1, 207: pp = 2, 307: pp = 3)
                 s3::g_tuning.gemm16_pp = (modes[c] / 100) % 10;
+                // column s0007 (s = 1 .. 25): mode 7 with every second workgroup of an XCD started 2 s microseconds late (round 6)
+                p.variant = 3 | (shared ? 8 : 0) | (((modes[c] / 10000) & 0xff) << 8);
                 const bool mx = split && modes[c] >= 1000 && !(sh.K & 127);  // column 1007: cmpx with the MX second term (gemm16.hip MXW)
                 p.wsplit = split && !mx ? 1 : 0;
                 p.ldw = split ? 2L * sh.K : 0;

@@ -6,7 +6,7 @@
 # usage: tools/round_profiles.sh r05        (most important artefacts first: a cut-off run still leaves them)
 #        PROFILE_ONLY="fp32 bf16" tools/round_profiles.sh r04   (PMC + rocprof only for the named configurations, bench lines for all)
 set -u
-tag=${1:-r05}
+tag=${1:-r06}
 export TMPDIR=/tmp
 out=gpurun_out/$tag
 mkdir -p $out
