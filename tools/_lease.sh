@@ -1,7 +1,4 @@
 set -u
 mkdir -p gpurun_out/r06
-export TMPDIR=/tmp
-( time python -m pytest tests -m gpu -q 2>&1 | tail -15 ) > gpurun_out/r06/gputests_full.log 2>&1
-tail -4 gpurun_out/r06/gputests_full.log
-bash tools/round_profiles.sh r06 > gpurun_out/r06/round_profiles.log 2>&1
-tail -5 gpurun_out/r06/round_profiles.log
+tools/micro/gemm16_lab cmp 7 20007 50007 100007 > gpurun_out/r06/gemm16_lab_skew.md 2>&1
+cat gpurun_out/r06/gemm16_lab_skew.md
