@@ -489,7 +489,8 @@ template <> struct RefM<true> {
     __device__ __forceinline__ void lower(float d) { s -= d; }
 };
 #ifndef S3_ATTN_EXP
-#define S3_ATTN_EXP 0  // lab switch (tools/micro/build.sh): 4 = the bias kernel with the scalar reference at three waves per SIMD
+#define S3_ATTN_EXP 0  // lab switches (tools/micro/build.sh): 1 = next-tile loads pinned, 4 = the bias kernel with the scalar reference at
+                       // three waves per SIMD, 8 = s_setprio(1) around a tile's work, 16 = the staged tile written to LDS mid-tile
 #endif
 constexpr bool attn_ref_scalar(bool bias) { return !bias || (S3_ATTN_EXP & 4); }
 constexpr int attn_h16_waves(bool bias) { return (bias && !(S3_ATTN_EXP & 4)) ? 2 : 3; }
@@ -684,6 +685,9 @@ __global__ __launch_bounds__(256, attn_h16_waves(BIAS)) void attn_h16_kernel(Att
         };
         f32x16 sc = scores(0);
         half_step(sc, 0);
+#if S3_ATTN_EXP & 16
+        if (FULL && !S3_PROBE(p, 1)) store_tile((kt + 1) & 1);  // (lab: the staged tile goes to its LDS buffer between the halves)
+#endif
         if (two) {
             sc = scores(1);
             half_step(sc, 1);
@@ -702,8 +706,19 @@ __global__ __launch_bounds__(256, attn_h16_waves(BIAS)) void attn_h16_kernel(Att
                 vp1 += tstride;
             }
             if (!S3_PROBE(p, 1)) load_tile();
+#if S3_ATTN_EXP & 1
+            __builtin_amdgcn_sched_barrier(0);  // (lab: the next tile's loads stay in front of this tile's work)
+#endif
+#if S3_ATTN_EXP & 8
+            __builtin_amdgcn_s_setprio(1);      // (lab: the multiplying wave ahead of its SIMD partners' loads and stores)
+#endif
             tile(std::true_type{}, kt);
+#if S3_ATTN_EXP & 8
+            __builtin_amdgcn_s_setprio(0);
+#endif
+#if !(S3_ATTN_EXP & 16)
             if (!S3_PROBE(p, 1)) store_tile((kt + 1) & 1);
+#endif
         } else {
             tile(std::false_type{}, kt);
         }
