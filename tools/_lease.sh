@@ -1,14 +1,8 @@
-python - <<'PY'
-import time, sys
-sys.path.insert(0,'.'); sys.path.insert(0,'tests')
-t=time.time(); import torch; print('import torch', round(time.time()-t,1))
-from conftest import load_golden
-from s3prl_amd.encoder import HipEncoder
-for name in ("hubert_large_s1_pl","hubert_base_s1_pl"):
-    t=time.time(); meta,cfg,w,wavs,g,_=load_golden(name); print(name,'load_golden (synth weights)', round(time.time()-t,2))
-    dev=[torch.from_numpy(x).cuda() for x in wavs]
-    for mode in ("fp32","fp32x3","fp16x2","fp16","bf16"):
-        t=time.time(); enc=HipEncoder(cfg,w,dtype=mode); t1=time.time()-t
-        t=time.time(); hs=enc.forward(dev).cpu(); t2=time.time()-t
-        enc.close(); print('  ',mode,'create',round(t1,2),'forward+copy',round(t2,2))
-PY
+set -u
+mkdir -p gpurun_out/r06
+export TMPDIR=/tmp
+( time python -m pytest tests -m gpu -q -x 2>&1 | tail -8 ) > gpurun_out/r06/gputests_final.log 2>&1
+tail -6 gpurun_out/r06/gputests_final.log
+python -c "import __graft_entry__ as g; g.smoke()"
+python bench.py > gpurun_out/r06/bench_default_final.json 2> gpurun_out/r06/bench_default_final.err
+cut -c1-400 gpurun_out/r06/bench_default_final.json
