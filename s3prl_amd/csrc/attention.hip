@@ -439,12 +439,32 @@ __global__ __launch_bounds__(256, 3) void attn_f32p_kernel(AttnParams p) {
 
 // ---- 16-bit operands ------------------------------------------------------------------------------------------
 // 64 keys per tile, K and V^T double-buffered in LDS, the next tile's global loads in flight (registers) while the
-// current one is multiplied: one barrier per 64 keys.  V is transposed on the way into LDS two keys at a time
-// (32-bit writes of a key pair per dim), so the A operand of O^T += V^T P^T is read as 8-byte vectors.
+// current one is multiplied: one barrier per 64 keys.  V was transposed on the way into LDS two keys at a time (32-bit
+// writes of a key pair per dim, 16 VALU + 8 LDS writes per thread and tile) so that the A operand of O^T += V^T P^T is read
+// as 8-byte vectors — still the persistent kernel's and the fp32x3 kernel's form; the one-shot kernel: switch 256 below.
+#ifndef S3_ATTN_EXP
+#define S3_ATTN_EXP 420  // lab switches (tools/micro/build.sh): 1 = next-tile loads pinned, 4 = the bias kernel with the scalar reference at
+                       // three waves per SIMD, 8 = s_setprio(1) around a tile's work, 16 = the staged tile written to LDS mid-tile,
+                       // 32 = the reference block from the matrix pipe (RefM<2>), 128 = 16-byte result stores (v_permlane32_swap
+                       // pairs), 256 = V row-major in LDS + ds_read_b64_tr_b16 (one-shot kernel).  Default 4 | 32 | 128 | 256 since
+                       // the second session of round 6 (profiles/r06b_attn_lab_variants.md); 0 rebuilds the first session's kernels
+#endif
 constexpr int KT16 = 64;         // keys per tile
 constexpr int KS16 = HD + 8;     // u16 per K row: 144 B rows -> conflict-free ds_read_b128
 constexpr int VS16 = KT16 + 4;   // u16 per V^T row: 136 B rows -> conflict-free ds_read_b64
 constexpr int KBUF16 = KT16 * KS16, VBUF16 = HD * VS16;
+// Lab switch 256 (round 6, second session): V stays ROW-MAJOR in LDS ([key][dim], two 16-byte writes per thread and tile like K — no
+// transposition on the VALU) and the A operand of O^T += V^T P^T is fetched with ds_read_b64_tr_b16: within a group of 16 lanes, lane
+// 4 j + r supplies the address of dims 4 r .. 4 r + 3 of key j and lane i receives dim i of keys 0..3.  160-byte rows: the four 32-byte
+// row pieces a lane group touches fall into four different bank octets.
+constexpr int VSR16 = HD + 16, VBUFR16 = KT16 * VSR16;
+constexpr bool ATTN_VTR = (S3_ATTN_EXP & 256) != 0;
+constexpr int VBUFX16 = ATTN_VTR ? VBUFR16 : VBUF16;
+__device__ __forceinline__ uint2 lds_tr16(const u16* p) {
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+    return __builtin_bit_cast(uint2, v);
+}
 
 template <typename T> struct Mma16;
 template <> struct Mma16<bf16_tag> {
@@ -462,22 +482,24 @@ template <> struct Mma16<f16_tag> {
 // the reference moves (the MFMA takes them as its C operand directly).  Scalar form (round 6): ONE register, the 16-register block is
 // filled from it per 32-key half (16 v_mov) — the bias-free kernel drops from 168 registers + 5 spilled to 144 and no spill, and its
 // compiler-made schedule gets 7-10 % faster (attn_lab: 62.4 -> 58.0 us HuBERT-base, 81.0 -> 73.1 HuBERT-large, 150 -> 139 WavLM-large
-// without bias; profiles/r06_attn_lab.md).  The bias kernel (two waves per SIMD, registers to spare) keeps the vector: there the
-// extra moves only cost (154 -> 168 us).  Same values either way: bit-identical.
-template <bool SCALAR> struct RefM;
-template <> struct RefM<false> {
+// without bias; profiles/r06_attn_lab.md).  With the vector form the bias kernel ran at two waves per SIMD (the scalar form at three:
+// 154 -> 168 us, the extra moves only cost).  Same values either way: bit-identical.  Since the second session of round 6 every 16-bit
+// kernel takes the matrix-pipe form below (RefM<2>), the bias kernel at three waves per SIMD with it (162 registers, no spill).
+template <int KIND, typename T> struct RefM;
+template <typename T> struct RefM<0, T> {
     f32x16 v;
     __device__ __forceinline__ void zero() {
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] = 0.f;
     }
     __device__ __forceinline__ f32x16 block() const { return v; }
-    __device__ __forceinline__ void lower(float d) {
+    __device__ __forceinline__ float lower(float d) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] -= d;
+        return d;
     }
 };
-template <> struct RefM<true> {
+template <typename T> struct RefM<1, T> {
     float s;
     __device__ __forceinline__ void zero() { s = 0.f; }
     __device__ __forceinline__ f32x16 block() const {
@@ -486,23 +508,96 @@ template <> struct RefM<true> {
         for (int r = 0; r < 16; ++r) x[r] = s;
         return x;
     }
-    __device__ __forceinline__ void lower(float d) { s -= d; }
+    __device__ __forceinline__ float lower(float d) {
+        s -= d;
+        return d;
+    }
 };
-#ifndef S3_ATTN_EXP
-#define S3_ATTN_EXP 0  // lab switches (tools/micro/build.sh): 1 = next-tile loads pinned, 4 = the bias kernel with the scalar reference at
-                       // three waves per SIMD, 8 = s_setprio(1) around a tile's work, 16 = the staged tile written to LDS mid-tile
+// Matrix-pipe form (round 6, second session): the block of -m comes out of ONE extra MFMA instead of 16 v_mov per 32-key half —
+// the kernel's compute phase is bound by VALU issue (profiles/r06_attn_lab.md) while the matrix pipe idles two thirds of it.  The
+// reference is kept as a two-term 16-bit number m = hi + lo (exact in the fp32 accumulator): the lower half-wave's A fragment
+// carries 1, 1 in k slots 0 and 1 (the upper half-wave's eight slots are zero), every lane's B fragment -hi, -lo of its query.
+// Softmax is invariant to the reference point, so rounding m to 16 + 16 bits costs nothing as long as every score, the rescale
+// factor and the running sum see the SAME m: lower() returns the step the reference really took.
+template <typename T> struct RefM<2, T> {
+    float m;        // the reference (= hi + lo exactly)
+    unsigned nb;    // B fragment word 0: (-hi, -lo)
+    unsigned a1;    // A fragment word 0: (1, 1) on lanes 0-31, 0 on lanes 32-63
+    __device__ __forceinline__ void zero() {
+        m = 0.f;
+        nb = 0u;
+        a1 = (threadIdx.x & 32) ? 0u : Cvt<T>::pack2(1.f, 1.f);
+    }
+    __device__ __forceinline__ f32x16 block() const {
+        f32x16 z;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[r] = 0.f;
+        return Mma16<T>::run(make_uint4(a1, 0u, 0u, 0u), make_uint4(nb, 0u, 0u, 0u), z);
+    }
+    __device__ __forceinline__ float lower(float d) {
+        const float want = m + d;
+        const float hi = Cvt<T>::from(Cvt<T>::to(want));
+        const float lo = Cvt<T>::from(Cvt<T>::to(want - hi));
+        const float m_new = hi + lo;
+        const float step = m_new - m;
+        m = m_new;
+        nb = Cvt<T>::pack2(-hi, -lo);
+        return step;
+    }
+};
+constexpr int attn_ref_kind(bool bias) { return (!bias || (S3_ATTN_EXP & 4)) ? ((S3_ATTN_EXP & 32) ? 2 : 1) : 0; }
+
+// maximum of the 16 scores a lane holds.  v_med3_f32(a, b, +inf) = max(a, b) without the canonicalising v_max that fmaxf puts on
+// every MFMA output; the compiler folds the chain into v_max3_f32 pairs itself.  (An inline-asm v_max3_f32 tree was tried and is
+// WRONG: the hazard recogniser does not count an asm statement as a reader of MFMA results, the required wait states are not
+// inserted and the tree reads accumulators that are still being written — f16 rows came out inf in tools/micro/attn_lab.)
+__device__ __forceinline__ float row_max16(const f32x16& sc) {
+    float mx = __builtin_amdgcn_fmed3f(sc[0], sc[1], INFINITY);
+#pragma unroll
+    for (int r = 2; r < 16; ++r) mx = __builtin_amdgcn_fmed3f(mx, sc[r], INFINITY);
+    return mx;
+}
+
+// the normalised 32 x 64 result of a wave as 16-bit rows.  A lane holds, of its query's row, the dims 8g + 4 half + {0..3} of both
+// 32-dim blocks: 8-byte pieces, eight stores.  Lab switch 128: v_permlane32_swap hands the lower half-wave the upper one's piece
+// of group g and the upper one the lower's piece of group g + 1, so that each lane owns 16 contiguous bytes: four stores.
+template <typename T>
+__device__ __forceinline__ void store_o16(u16* row, int half, const f32x16& o0, const f32x16& o1, float inv) {
+#if S3_ATTN_EXP & 128
+    u16* op = row + 8 * half;
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+        const f32x16& o = blk ? o1 : o0;
+#pragma unroll
+        for (int g = 0; g < 4; g += 2) {
+            unsigned ax = Cvt<T>::pack2(o[4 * g] * inv, o[4 * g + 1] * inv), ay = Cvt<T>::pack2(o[4 * g + 2] * inv, o[4 * g + 3] * inv);
+            unsigned bx = Cvt<T>::pack2(o[4 * g + 4] * inv, o[4 * g + 5] * inv), by = Cvt<T>::pack2(o[4 * g + 6] * inv, o[4 * g + 7] * inv);
+            const auto rx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+            const auto ry = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+            *(uint4*)(op + 32 * blk + 8 * g) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
+        }
+    }
+#else
+    u16* op = row + 4 * half;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        *(uint2*)(op + 8 * g) = make_uint2(Cvt<T>::pack2(o0[4 * g] * inv, o0[4 * g + 1] * inv),
+                                           Cvt<T>::pack2(o0[4 * g + 2] * inv, o0[4 * g + 3] * inv));
+        *(uint2*)(op + 32 + 8 * g) = make_uint2(Cvt<T>::pack2(o1[4 * g] * inv, o1[4 * g + 1] * inv),
+                                                Cvt<T>::pack2(o1[4 * g + 2] * inv, o1[4 * g + 3] * inv));
+    }
 #endif
-constexpr bool attn_ref_scalar(bool bias) { return !bias || (S3_ATTN_EXP & 4); }
+}
 constexpr int attn_h16_waves(bool bias) { return (bias && !(S3_ATTN_EXP & 4)) ? 2 : 3; }
 
-// BIAS: the WavLM relative-position bias path compiled in (its 16 table reads in flight need > 168 registers: two waves per
-// SIMD); the bias-free variant fits 152 registers = 3 waves per SIMD.
+// BIAS: the WavLM relative-position bias path compiled in (with a 16-register reference block its 16 table reads in flight need
+// > 168 registers: two waves per SIMD; with the matrix-pipe reference 162 = three); the bias-free variant: 144 registers.
 // Operand contract of the 16-bit kernels: q arrives pre-scaled by head_dim^-0.5 * log2(e) (folded into W_q / b_q at pack
 // time), so the scores are base-2 logarithms and the softmax is exp2 without a per-score multiply.
 template <typename T, bool BIAS>
 __global__ __launch_bounds__(256, attn_h16_waves(BIAS)) void attn_h16_kernel(AttnParams p) {
     __shared__ __attribute__((aligned(16))) u16 Ks[2 * KBUF16];
-    __shared__ __attribute__((aligned(16))) u16 Vt[2 * VBUF16];
+    __shared__ __attribute__((aligned(16))) u16 Vt[2 * VBUFX16];
     const AttnWork wk = attn_work(p);
     if (!wk.live) return;
     const int b = wk.b, head = wk.head;
@@ -549,7 +644,7 @@ __global__ __launch_bounds__(256, attn_h16_waves(BIAS)) void attn_h16_kernel(Att
     //   * one 32-key score tile is live at a time: with both halves' chains in flight (and their K / V fragments
     //     pre-loaded) the kernel needs 216 registers = two waves per SIMD, and was slower than this form at three.
     f32x16 o0, o1;
-    RefM<attn_ref_scalar(BIAS)> negm;
+    RefM<attn_ref_kind(BIAS), T> negm;
     negm.zero();
 #pragma unroll
     for (int r = 0; r < 16; ++r) o0[r] = o1[r] = 0.f;
@@ -569,8 +664,13 @@ __global__ __launch_bounds__(256, attn_h16_waves(BIAS)) void attn_h16_kernel(Att
         const int k0_ = kt * KT16;
         kp0 = base + (long)clampk(k0_ + krow) * ld + D + kc8 * 8;
         kp1 = base + (long)clampk(k0_ + krow + 32) * ld + D + kc8 * 8;
-        vp0 = base + (long)clampk(k0_ + 2 * vj) * ld + 2 * D + vdg * 8;
-        vp1 = base + (long)clampk(k0_ + 2 * vj + 1) * ld + 2 * D + vdg * 8;
+        if (ATTN_VTR) {
+            vp0 = base + (long)clampk(k0_ + krow) * ld + 2 * D + kc8 * 8;
+            vp1 = base + (long)clampk(k0_ + krow + 32) * ld + 2 * D + kc8 * 8;
+        } else {
+            vp0 = base + (long)clampk(k0_ + 2 * vj) * ld + 2 * D + vdg * 8;
+            vp1 = base + (long)clampk(k0_ + 2 * vj + 1) * ld + 2 * D + vdg * 8;
+        }
     };
     auto load_tile = [&]() {
         kreg[0] = *(const u32x4*)kp0;
@@ -579,12 +679,17 @@ __global__ __launch_bounds__(256, attn_h16_waves(BIAS)) void attn_h16_kernel(Att
         vreg[1] = *(const u32x4*)vp1;
     };
     u16* const ks_st = Ks + krow * KS16 + kc8 * 8;
-    u16* const vt_st = Vt + (vdg * 8) * VS16 + 2 * vj;
+    u16* const vt_st = ATTN_VTR ? Vt + krow * VSR16 + kc8 * 8 : Vt + (vdg * 8) * VS16 + 2 * vj;
     auto store_tile = [&](int buf) {
         u16* ks_ = ks_st + buf * KBUF16;
-        u16* vt_ = vt_st + buf * VBUF16;
+        u16* vt_ = vt_st + buf * VBUFX16;
         *(u32x4*)ks_ = kreg[0];
         *(u32x4*)(ks_ + 32 * KS16) = kreg[1];
+        if (ATTN_VTR) {
+            *(u32x4*)vt_ = vreg[0];
+            *(u32x4*)(vt_ + 32 * VSR16) = vreg[1];
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const unsigned a_ = vreg[0][i], b_ = vreg[1][i];
@@ -598,13 +703,14 @@ __global__ __launch_bounds__(256, attn_h16_waves(BIAS)) void attn_h16_kernel(Att
     __syncthreads();
     const long tstride = (long)KT16 * ld;  // elements between the same row of consecutive tiles
     const u16* const kf_rd = Ks + l31 * KS16 + 8 * half;
-    const u16* const vf_rd = Vt + l31 * VS16 + 4 * half;
+    const u16* const vf_rd = ATTN_VTR ? Vt + (4 * half + ((lane & 15) >> 2)) * VSR16 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3)
+                                      : Vt + l31 * VS16 + 4 * half;
 
     // one 64-key tile.  FULL: every key is valid (all tiles but the last)
     auto tile = [&](auto full_c, int kt) {
         constexpr bool FULL = decltype(full_c)::value;
         const u16* ks = kf_rd + (kt & 1) * KBUF16;
-        const u16* vt = vf_rd + (kt & 1) * VBUF16;
+        const u16* vt = vf_rd + (kt & 1) * VBUFX16;
         const bool two = FULL || kt * KT16 + 32 < valid;  // wave-uniform: the second half has at least one valid key
         auto scores = [&](int h) {
             f32x16 sc = negm.block();
@@ -631,13 +737,10 @@ __global__ __launch_bounds__(256, attn_h16_waves(BIAS)) void attn_h16_kernel(Att
             if (S3_PROBE(p, 2)) goto pv;
             {
             // max of the 16 scores as v_med3_f32(a, b, +inf): fmaxf on MFMA outputs costs a canonicalising v_max per input
-            float mx = __builtin_amdgcn_fmed3f(sc[0], sc[1], INFINITY);
-#pragma unroll
-            for (int r = 2; r < 16; ++r) mx = __builtin_amdgcn_fmed3f(mx, sc[r], INFINITY);
-            mx = xhalf_max(mx);
+            const float mx = xhalf_max(row_max16(sc));
             if (__builtin_expect(first || __any(mx > 8.f), 0)) {
                 // move the reference: exactly onto the maximum for the first keys of a row, up by the excess afterwards
-                const float delta = first ? mx : fmaxf(mx, 0.f);
+                const float delta = negm.lower(first ? mx : fmaxf(mx, 0.f));  // (the step the reference really takes)
                 // first: O = l = 0 and the scale must be exactly 1 — exp2(-mx) overflows to +inf when every log2-domain score of
                 // the half is below -128 (q . b_k is softmax-invariant, so nothing bounds it) and 0 * inf would poison the row
                 const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);
@@ -647,7 +750,6 @@ __global__ __launch_bounds__(256, attn_h16_waves(BIAS)) void attn_h16_kernel(Att
                     o1[r] *= alpha;
                     sc[r] -= delta;
                 }
-                negm.lower(delta);
                 l_run *= alpha;
                 first = false;
             }
@@ -676,9 +778,16 @@ __global__ __launch_bounds__(256, attn_h16_waves(BIAS)) void attn_h16_kernel(Att
                 pf.y = Cvt<T>::pack2(sc[8 * u + 2], sc[8 * u + 3]);
                 pf.z = Cvt<T>::pack2(sc[8 * u + 4], sc[8 * u + 5]);
                 pf.w = Cvt<T>::pack2(sc[8 * u + 6], sc[8 * u + 7]);
-                const u16* v0 = vt + 32 * h + 16 * u;
-                const uint2 a00 = *(const uint2*)(v0), a01 = *(const uint2*)(v0 + 8);
-                const uint2 a10 = *(const uint2*)(v0 + 32 * VS16), a11 = *(const uint2*)(v0 + 32 * VS16 + 8);
+                uint2 a00, a01, a10, a11;
+                if (ATTN_VTR) {
+                    const u16* v0 = vt + (32 * h + 16 * u) * VSR16;
+                    a00 = lds_tr16(v0), a01 = lds_tr16(v0 + 8 * VSR16);
+                    a10 = lds_tr16(v0 + 32), a11 = lds_tr16(v0 + 8 * VSR16 + 32);
+                } else {
+                    const u16* v0 = vt + 32 * h + 16 * u;
+                    a00 = *(const uint2*)(v0), a01 = *(const uint2*)(v0 + 8);
+                    a10 = *(const uint2*)(v0 + 32 * VS16), a11 = *(const uint2*)(v0 + 32 * VS16 + 8);
+                }
                 o0 = Mma16<T>::run(make_uint4(a00.x, a00.y, a01.x, a01.y), pf, o0);
                 o1 = Mma16<T>::run(make_uint4(a10.x, a10.y, a11.x, a11.y), pf, o1);
             }
@@ -736,16 +845,7 @@ __global__ __launch_bounds__(256, attn_h16_waves(BIAS)) void attn_h16_kernel(Att
         }
         return;
     }
-    if (q_g < p.T) {
-        u16* op = (u16*)p.out + ((long)b * p.T + q_g) * D + head * HD + 4 * half;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            *(uint2*)(op + 8 * g) = make_uint2(Cvt<T>::pack2(o0[4 * g] * inv, o0[4 * g + 1] * inv),
-                                               Cvt<T>::pack2(o0[4 * g + 2] * inv, o0[4 * g + 3] * inv));
-            *(uint2*)(op + 32 + 8 * g) = make_uint2(Cvt<T>::pack2(o1[4 * g] * inv, o1[4 * g + 1] * inv),
-                                                    Cvt<T>::pack2(o1[4 * g + 2] * inv, o1[4 * g + 3] * inv));
-        }
-    }
+    if (q_g < p.T) store_o16<T>((u16*)p.out + ((long)b * p.T + q_g) * D + head * HD, half, o0, o1, inv);
 }
 
 // ---- round 6: the persistent form of the 16-bit kernel ----------------------------------------------------------------------
@@ -868,7 +968,7 @@ __global__ __launch_bounds__(256, attn_h16_waves(BIAS)) void attn_h16p_kernel(At
     int buf = 0;  // the LDS buffer the next tile to multiply sits in (runs on across items)
 
     f32x16 o0, o1;
-    RefM<attn_ref_scalar(BIAS)> negm;
+    RefM<attn_ref_kind(BIAS), T> negm;
     float l_run;
     bool first;
     while (true) {
@@ -907,12 +1007,9 @@ __global__ __launch_bounds__(256, attn_h16_waves(BIAS)) void attn_h16p_kernel(At
                 }
                 if (S3_PROBE(p, 2)) goto pv;
                 {
-                float mx = __builtin_amdgcn_fmed3f(sc[0], sc[1], INFINITY);
-#pragma unroll
-                for (int r = 2; r < 16; ++r) mx = __builtin_amdgcn_fmed3f(mx, sc[r], INFINITY);
-                mx = xhalf_max(mx);
+                const float mx = xhalf_max(row_max16(sc));
                 if (__builtin_expect(first || __any(mx > 8.f), 0)) {
-                    const float delta = first ? mx : fmaxf(mx, 0.f);
+                    const float delta = negm.lower(first ? mx : fmaxf(mx, 0.f));  // (the step the reference really takes)
                     const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);  // (first: see attn_h16_kernel)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
@@ -920,7 +1017,6 @@ __global__ __launch_bounds__(256, attn_h16_waves(BIAS)) void attn_h16p_kernel(At
                         o1[r] *= alpha;
                         sc[r] -= delta;
                     }
-                    negm.lower(delta);
                     l_run *= alpha;
                     first = false;
                 }
@@ -993,7 +1089,7 @@ __global__ __launch_bounds__(256, attn_h16_waves(BIAS)) void attn_h16p_kernel(At
         const float inv = 1.f / xhalf_sum(l_run);
         const bool q_ok = q_g < p.T;
         const long obase = (long)cur.b * p.T * D + cur.head * HD;  // (wave-uniform)
-        const unsigned orow = (unsigned)(q_g * D + 4 * half);
+        const unsigned orow = (unsigned)(q_g * D);  // (q_g is the NEXT item's after enter_scalars below)
         if (has_next) {
             store_tile(buf ^ 1);  // (frees the staging registers)
             enter_scalars(nx);    // (q_g / q_c / valid / ntiles now belong to the next item)
@@ -1001,7 +1097,7 @@ __global__ __launch_bounds__(256, attn_h16_waves(BIAS)) void attn_h16p_kernel(At
         }
         if (p.out_f32) {  // (workgroup-uniform)
             if (q_ok) {
-                float* op = (float*)p.out + obase + orow;
+                float* op = (float*)p.out + obase + orow + 4 * half;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     *(float4*)(op + 8 * g) = make_float4(o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
@@ -1009,14 +1105,7 @@ __global__ __launch_bounds__(256, attn_h16_waves(BIAS)) void attn_h16p_kernel(At
                 }
             }
         } else if (q_ok) {
-            u16* op = (u16*)p.out + obase + orow;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                *(uint2*)(op + 8 * g) = make_uint2(Cvt<T>::pack2(o0[4 * g] * inv, o0[4 * g + 1] * inv),
-                                                   Cvt<T>::pack2(o0[4 * g + 2] * inv, o0[4 * g + 3] * inv));
-                *(uint2*)(op + 32 + 8 * g) = make_uint2(Cvt<T>::pack2(o1[4 * g] * inv, o1[4 * g + 1] * inv),
-                                                        Cvt<T>::pack2(o1[4 * g + 2] * inv, o1[4 * g + 3] * inv));
-            }
+            store_o16<T>((u16*)p.out + obase + orow, half, o0, o1, inv);
         }
         if (!has_next) break;
         __syncthreads();  // every wave is past its last tile: the other K / V buffer (and the bias window) may be re-used

@@ -5,8 +5,9 @@
 set -e
 cd "$(dirname "$0")/../.."
 H="hipcc -O3 -std=c++17 --offload-arch=gfx950"
-$H -DS3_ATTN_PROBE -Is3prl_amd/csrc tools/micro/attn_lab.hip -o tools/micro/attn_lab
-$H -DS3_ATTN_PROBE -DS3_ATTN_EXP=4 -Is3prl_amd/csrc tools/micro/attn_lab.hip -o tools/micro/attn_lab_e4   # (the bias kernel: scalar reference, three waves per SIMD)
+$H -DS3_ATTN_PROBE -Is3prl_amd/csrc tools/micro/attn_lab.hip -o tools/micro/attn_lab                    # (the timing probes compiled in: +20 registers)
+$H -Is3prl_amd/csrc tools/micro/attn_lab.hip -o tools/micro/attn_lab_product                              # the library's code: QUICK=1 SKIP_F32=1
+$H -DS3_ATTN_EXP=0 -Is3prl_amd/csrc tools/micro/attn_lab.hip -o tools/micro/attn_lab_x0                   # (the kernels before the second session of round 6)
 $H -DS3_GEMM_PROBE -DS3_GEMM_PP_LAB -Is3prl_amd/csrc tools/micro/gemm16_lab.hip -o tools/micro/gemm16_lab
 $H tools/micro/gemm16_loop_probe.hip -o tools/micro/gemm16_loop_probe
 $H tools/micro/gemm_loop_probe.hip -o tools/micro/gemm_loop_probe
