@@ -107,10 +107,94 @@ __global__ __launch_bounds__(256) void gn_lag_kernel(WavTable w, const float2* n
     }
 }
 
+// The same numbers from ONE block per (chunk, utterance) (round 6, second session).  gn_lag_kernel above runs k0 blocks per chunk, each
+// re-reading the chunk's PCM at a 20-byte lane stride (11 scattered loads per frame) and reducing its 17 accumulators one
+// __syncthreads pair at a time: 95.7 us per forward under rocprofv3 for 20 MB of PCM (profiles/r06_kernel_stats_bf16.md).  Here the window of
+// 1024 frames is staged in LDS with coalesced loads and normalised once, a thread keeps S[K0] and the UPPER triangle of R in registers
+// (x_j x_jj is an exact fp64 product of two floats, so R[jj][j] is the same sum in the same order as R[j][jj]: mirrored on the way out)
+// and all wave sums cross the block in one exchange.  Same frames per thread in the same order, same butterfly, same four-wave sum:
+// bit-identical to gn_lag_kernel (tests/test_ops_gpu.py::test_gn_stats_one_block_form_is_bit_identical).
+constexpr int GN_SUB = 1024;  // frames staged at a time (a divisor of GN_FRAMES, a multiple of the block)
+template <int K0>
+__global__ __launch_bounds__(256) void gn_lag_all_kernel(WavTable w, const float2* norm, int s0, long L0, double* partial, int chunks) {
+    constexpr int NR = K0 * (K0 + 1) / 2, NACC = K0 + NR;
+    __shared__ float win[(GN_SUB - 1) * 8 + K0];  // stride <= 8 (launcher)
+    __shared__ double red[4][NACC];
+    const int ch = blockIdx.x, b = blockIdx.y;
+    const float* x = w.ptrs[b];
+    const long len = w.lens[b];
+    const float mean = norm[b].x, rstd = norm[b].y;
+    const long t_beg = (long)ch * GN_FRAMES;
+    long t_end = t_beg + GN_FRAMES;
+    t_end = t_end < L0 ? t_end : L0;
+    double S[K0], R[NR];
+#pragma unroll
+    for (int j = 0; j < K0; ++j) S[j] = 0;
+#pragma unroll
+    for (int e = 0; e < NR; ++e) R[e] = 0;
+    for (long u_beg = t_beg; u_beg < t_end; u_beg += GN_SUB) {
+        const int nfr = (int)((t_end - u_beg) < GN_SUB ? (t_end - u_beg) : GN_SUB);
+        const int nwin = (nfr - 1) * s0 + K0;
+        __syncthreads();  // (the previous window has been consumed)
+        // eight loads in flight per thread (a plain loop compiles to one load + s_waitcnt vmcnt(0) per element: 20 serial round trips
+        // per window)
+        const long pos0 = u_beg * s0;
+        for (int i0 = threadIdx.x; i0 < nwin; i0 += 8 * 256) {
+            float raw[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * 256;
+                raw[u] = (i < nwin && pos0 + i < len) ? x[pos0 + i] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * 256;
+                if (i < nwin) win[i] = pos0 + i < len ? (raw[u] - mean) * rstd : 0.f;  // (= load_wav)
+            }
+        }
+        __syncthreads();
+        for (int t = threadIdx.x; t < nfr; t += 256) {  // (frames t_beg + tid + 256 i, i ascending: gn_lag_kernel's order)
+            double xv[K0];
+#pragma unroll
+            for (int j = 0; j < K0; ++j) xv[j] = (double)win[t * s0 + j];
+            int e = 0;
+#pragma unroll
+            for (int j = 0; j < K0; ++j) {
+                S[j] += xv[j];
+#pragma unroll
+                for (int jj = j; jj < K0; ++jj) R[e++] += xv[j] * xv[jj];
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < K0; ++j) {
+        const double v = wave_sum_d(S[j]);
+        if (lane == 0) red[wave][j] = v;
+    }
+#pragma unroll
+    for (int e = 0; e < NR; ++e) {
+        const double v = wave_sum_d(R[e]);
+        if (lane == 0) red[wave][K0 + e] = v;
+    }
+    __syncthreads();
+    // thread (j, jj): partial[b][chunk][j][0] = S[j], [1 + jj] = R[min][max]
+    for (int o = threadIdx.x; o < K0 * (1 + K0); o += 256) {
+        const int j = o / (1 + K0), c = o % (1 + K0);
+        int a;
+        if (c == 0) a = j;
+        else {
+            const int jj = c - 1, lo = j < jj ? j : jj, hi = j < jj ? jj : j;
+            a = K0 + lo * K0 - lo * (lo - 1) / 2 + (hi - lo);
+        }
+        partial[(((long)b * chunks + ch) * K0 + j) * ROWLEN + c] = ((red[0][a] + red[1][a]) + red[2][a]) + red[3][a];
+    }
+}
+
 __global__ __launch_bounds__(256) void gn_final_kernel(const double* partial, int chunks, int k0, long L0, const float* w0,
                                                        const float* gamma, const float* beta, int C, float2* gn) {
     __shared__ double sums[STAT_K0_MAX * ROWLEN];
-    const int b = blockIdx.x;
+    const int b = blockIdx.x;  // (blockIdx.y: a slab of 256 channels; every slab rebuilds the 110 sums — cheaper than a second launch)
     for (int e = threadIdx.x; e < k0 * ROWLEN; e += 256) {
         double s = 0;
         for (int c = 0; c < chunks; ++c) s += partial[((long)b * chunks + c) * k0 * ROWLEN + e];
@@ -118,14 +202,22 @@ __global__ __launch_bounds__(256) void gn_final_kernel(const double* partial, in
     }
     __syncthreads();
     const double inv = 1.0 / (double)L0;
-    for (int c = threadIdx.x; c < C; c += 256) {
+    for (int c = blockIdx.y * 256 + threadIdx.x; c < C; c += 256 * gridDim.y) {
         double m = 0, e2 = 0;
-        for (int j = 0; j < k0; ++j) {
-            const double wj = w0[c * k0 + j];
-            m += wj * sums[j * ROWLEN];
-            double r = 0;
-            for (int jj = 0; jj < k0; ++jj) r += (double)w0[c * k0 + jj] * sums[j * ROWLEN + 1 + jj];
-            e2 += wj * r;
+        double wd[STAT_K0_MAX];  // (the channel's taps once, in registers: the loop below re-read each of them k0 times from memory)
+#pragma unroll
+        for (int j = 0; j < STAT_K0_MAX; ++j) wd[j] = j < k0 ? (double)w0[c * k0 + j] : 0.0;
+#pragma unroll
+        for (int j = 0; j < STAT_K0_MAX; ++j) {
+            if (j < k0) {
+                const double wj = wd[j];
+                m += wj * sums[j * ROWLEN];
+                double r = 0;
+#pragma unroll
+                for (int jj = 0; jj < STAT_K0_MAX; ++jj)
+                    if (jj < k0) r += wd[jj] * sums[j * ROWLEN + 1 + jj];
+                e2 += wj * r;
+            }
         }
         m *= inv;
         e2 *= inv;
@@ -325,8 +417,11 @@ hipError_t launch_gn_stats(const WavTable& w, const float2* norm, const float* w
                            int C, int k0, int s0, long L0, double* partial, double* /*sums*/, float2* gn, hipStream_t s) {
     if (k0 > STAT_K0_MAX) return hipErrorInvalidValue;
     const int chunks = (int)((L0 + GN_FRAMES - 1) / GN_FRAMES);
-    hipLaunchKernelGGL(gn_lag_kernel, dim3(chunks, w.B, k0), dim3(256), 0, s, w, norm, k0, s0, L0, partial, chunks);
-    hipLaunchKernelGGL(gn_final_kernel, dim3(w.B), dim3(256), 0, s, partial, chunks, k0, L0, w0, gamma, beta, C, gn);
+    if (k0 == 10 && s0 >= 1 && s0 <= 8 && tuning().gn_lag_one_block)
+        hipLaunchKernelGGL(gn_lag_all_kernel<10>, dim3(chunks, w.B), dim3(256), 0, s, w, norm, s0, L0, partial, chunks);
+    else
+        hipLaunchKernelGGL(gn_lag_kernel, dim3(chunks, w.B, k0), dim3(256), 0, s, w, norm, k0, s0, L0, partial, chunks);
+    hipLaunchKernelGGL(gn_final_kernel, dim3(w.B, (C + 255) / 256), dim3(256), 0, s, partial, chunks, k0, L0, w0, gamma, beta, C, gn);
     return hipGetLastError();
 }
 

@@ -48,7 +48,9 @@ struct Tuning {
     int attn_persist = 0;  // attention.hip: 1 = persistent workgroups that fetch the next (batch, head, query block) item's Q and first
                            // K / V tile under the current item's last tile (round 6; bit-identical).  MEASURED AND LEFT OFF: the 16-bit
                            // form is 20-30 % slower than the one-shot grid (lab 58 -> 78 us, forward 48.7 -> 53.3 us per launch), the
-                           // fp32 form -7 % in the lab and +0.7 % in the forward (profiles/r06_attn_lab.md, r06_attention_persist.md)
+                           // fp32 form -7 % in the lab and +0.7 % in the forward (profiles/r06_attn_lab.md, r06_attention_persist.md);
+                           // against the one-shot kernel of the second session: 43.6 vs 38.5 us HuBERT-base, 54.8 vs 50.4 HuBERT-large,
+                           // 110 vs 107 / 130 vs 121 WavLM-large (profiles/r06b_attn_lab_variants.md)
     int conv0_nt = 1;      // frontend.hip, fp32 output: 1 = non-temporal row stores (the 2 GB activation streams past the caches:
                            // 0.578 -> 0.436 ms on HuBERT-base 32 x 10 s, round 4), 0 = plain stores
     int ws_inplace = 1;    // engine.hip, post-LN layers: 1 = LayerNorm 1 and fc2 work in place on ONE fp32 buffer (49 MB less
@@ -56,6 +58,8 @@ struct Tuning {
     int gelu32 = 1;        // S3ENC_F32: 1 = the one-transcendental GELU of every mode (common.h gelu_fast; fp32 rounding level), 0 = libm erff
     int x3_pack_cache = 0; // s3enc_op_gemm(S3ENC_F32X3): keep the packed image of the last weight (micro-benchmarks)
     int fp16x2_conv1_f32 = 0;  // engine.hip, S3ENC_F16X2 (read at s3enc_create): 1 = conv0 writes fp32 and conv1 runs on the three-term GEMM too
+    int gn_lag_one_block = 1;  // frontend.hip: 1 = GroupNorm lag sums from ONE workgroup per (4096-frame chunk, utterance) over an LDS-staged
+                           // window (bit-identical to the k0-workgroups form, 95.7 -> see profiles/r06b_gn_stats.md), 0 = the earlier kernel
     int comm_self_p2p = 0; // comm.hip, S3ENC_EXCHANGE_DIRECT: 1 = a rank's OWN block also travels as an ncclSend-to-self / ncclRecv-from-self
                            // pair inside the state's group instead of a device copy — on a one-GPU box this is the only way the
                            // all-pairs code (symbols, counts, datatype, group bracketing, stream order behind the layer events)

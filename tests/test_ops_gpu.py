@@ -538,6 +538,43 @@ def _conv0_ref(wavs, n_max, normalize, w0, bias, gn, ln, stride):
     return O.gelu(y)
 
 
+@pytest.mark.parametrize("normalize", [0, 1])
+@pytest.mark.parametrize("stride", [5, 3])
+def test_gn_stats_one_block_form_is_bit_identical(normalize, stride):
+    """Round 6 (second session), tuning key `gn_lag_one_block` (default 1): the GroupNorm lag sums from ONE workgroup per (4096-frame chunk,
+    utterance) over an LDS-staged window — same frames per thread in the same order, the upper triangle of R mirrored (x_j x_jj is an exact
+    fp64 product), same butterfly and four-wave sum — must reproduce the k0-workgroups kernel bit for bit: conv0's GroupNorm'd output is
+    compared as raw bits on utterances that span several chunks, end inside a staging window, and one that is shorter than a window."""
+    torch = _torch()
+    from s3prl_amd import _lib
+
+    lib = _lib.load()
+    rng = np.random.default_rng(97 + stride + normalize)
+    C_ = 512
+    lens = [5 * 4096 * 2 + 1777, 5 * 4096 + 9, 5 * 1024 * 3 + 2, 333, 5 * 4096 * 2 + 1776]
+    wavs = [(2.0 * rng.standard_normal(n) + 0.3).astype(np.float32) for n in lens]
+    w0 = (rng.standard_normal((C_, 10)) * 0.5).astype(np.float32)
+    g = (1 + 0.1 * rng.standard_normal(C_)).astype(np.float32)
+    bt = (0.05 * rng.standard_normal(C_)).astype(np.float32)
+    L0 = (max(lens) - 10) // stride + 1
+    dw = [_dev(w) for w in wavs]
+    ptrs = (C.c_void_p * len(dw))(*[t.data_ptr() for t in dw])
+    ln_ = (C.c_int64 * len(dw))(*lens)
+    dw0, dg, db = _dev(w0), _dev(g), _dev(bt)
+    outs = []
+    try:
+        for one_block in (0, 1):
+            _lib.check(lib.s3enc_set_tuning(b"gn_lag_one_block", one_block))
+            out = torch.full((len(lens), L0, C_), float("nan"), device="cuda", dtype=torch.float32)
+            _lib.check(lib.s3enc_op_conv0(_lib.DTYPES["fp32"], ptrs, ln_, len(lens), 0, normalize, _ptr(dw0), None, _ptr(dg), _ptr(db), None,
+                                          None, C_, stride, _ptr(out), None), "s3enc_op_conv0")
+            torch.cuda.synchronize()
+            outs.append(out.view(torch.int32).cpu().numpy())
+    finally:
+        _lib.check(lib.s3enc_set_tuning(b"gn_lag_one_block", 1))
+    assert np.array_equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 @pytest.mark.parametrize("case", ["unit", "dc_offset", "pcm_int16", "ragged_norm", "layer_norm", "layer_norm_bias"])
 def test_conv0_groupnorm_layernorm(dtype, case):
