@@ -58,6 +58,10 @@ struct Tuning {
     int gelu32 = 1;        // S3ENC_F32: 1 = the one-transcendental GELU of every mode (common.h gelu_fast; fp32 rounding level), 0 = libm erff
     int x3_pack_cache = 0; // s3enc_op_gemm(S3ENC_F32X3): keep the packed image of the last weight (micro-benchmarks)
     int fp16x2_conv1_f32 = 0;  // engine.hip, S3ENC_F16X2 (read at s3enc_create): 1 = conv0 writes fp32 and conv1 runs on the three-term GEMM too
+    int ln_rows = 1;       // norm.hip: rows per wave of the row LayerNorm.  2 = both rows' loads in flight before the first reduction (launches of
+                           // >= 8192 rows; bit-identical by test).  MEASURED AND LEFT OFF (round 6, second session, same lease, HuBERT-base
+                           // 32 x 10 s): LN1 + LN2 0.536 -> 0.551 ms per bf16 forward, 0.513 -> 0.529 fp32 — the kernel is at the memory
+                           // side's rate (5.3-6.1 TB/s), not short of loads in flight
     int gn_lag_one_block = 1;  // frontend.hip: 1 = GroupNorm lag sums from ONE workgroup per (4096-frame chunk, utterance) over an LDS-staged
                            // window (bit-identical to the k0-workgroups form, 95.7 -> see profiles/r06b_gn_stats.md), 0 = the earlier kernel
     int comm_self_p2p = 0; // comm.hip, S3ENC_EXCHANGE_DIRECT: 1 = a rank's OWN block also travels as an ncclSend-to-self / ncclRecv-from-self

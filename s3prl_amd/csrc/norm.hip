@@ -12,24 +12,34 @@
 namespace s3 {
 namespace {
 
-template <typename T, int NCH>
+// R rows per wave (round 6, second session): with one row per wave a wave is one memory round trip, a reduction and a store burst —
+// 3 KB in flight per wave, ~6 MB per chip, 5.3-6.1 TB/s; R = 2 issues both rows' loads before the first reduction (same per-row
+// arithmetic in the same order: bit-identical; an in-place call still reads every row it owns before it writes one).  Measured:
+// 2-3 % SLOWER (tuning key ln_rows, default 1) — the kernel is not short of loads in flight.
+template <typename T, int NCH, int R>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, long rows, int C, int act,
                                                         float* out32, void* out16, LnAcc fa, LnGate gt, int* status) {
     typedef typename Cvt<T>::store_t store_t;
-    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
+    const long row0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+    if (row0 >= rows) return;
     const int lane = threadIdx.x & 63;
     const int nch = C >> 2;
-    const float* xr = x + row * C;
-    float4 v[NCH];
-    float s = 0.f;
+    float4 vv[R][NCH];
+    float ss[R];
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-        const int ch = lane + 64 * i;
-        v[i] = ch < nch ? *(const float4*)(xr + 4 * ch) : make_float4(0.f, 0.f, 0.f, 0.f);
-        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    for (int r = 0; r < R; ++r) {
+        const long row = row0 + r < rows ? row0 + r : rows - 1;  // (a row past the end re-reads the last one and is not processed)
+        const float* xr = x + row * C;
+        ss[r] = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int ch = lane + 64 * i;
+            vv[r][i] = ch < nch ? *(const float4*)(xr + 4 * ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+            ss[r] += (vv[r][i].x + vv[r][i].y) + (vv[r][i].z + vv[r][i].w);
+        }
     }
+    auto do_row = [&](const long row, float4 (&v)[NCH], const float s) {
     const float invC = 1.f / (float)C;
     const float mu = wave_sum(s) * invC;
     float q = 0.f;
@@ -155,6 +165,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
             *dst = t;
         }
     }
+    };
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        if (row0 + r < rows) do_row(row0 + r, vv[r], ss[r]);
 }
 
 // Standalone state emission for producers that are not a LayerNorm: a row of a state -> its 16-bit copy in the caller's
@@ -233,13 +247,19 @@ template <typename T>
 hipError_t ln_dispatch(const float* x, const float* gamma, const float* beta, long rows, int C, int act, float* out32,
                        void* out16, const LnAcc& fa, const LnGate& gt, hipStream_t s) {
     const int per_lane = ((C >> 2) + 63) / 64;
-    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
-#define S3_LN(N) hipLaunchKernelGGL((layernorm_kernel<T, N>), grid, block, 0, s, x, gamma, beta, rows, C, act, out32, out16, fa, gt, t_status)
-    if (per_lane <= 1) S3_LN(1);
-    else if (per_lane == 2) S3_LN(2);
-    else if (per_lane == 3) S3_LN(3);
-    else if (per_lane == 4) S3_LN(4);
-    else S3_LN(8);
+    const int R = (tuning().ln_rows == 2 && per_lane <= 4 && rows >= 8192) ? 2 : 1;  // (two rows per wave only where the grid still fills the chip)
+    dim3 grid((unsigned)((rows + 4 * R - 1) / (4 * R))), block(256);
+#define S3_LN(N, RR) hipLaunchKernelGGL((layernorm_kernel<T, N, RR>), grid, block, 0, s, x, gamma, beta, rows, C, act, out32, out16, fa, gt, t_status)
+    if (R == 2) {
+        if (per_lane <= 1) S3_LN(1, 2);
+        else if (per_lane == 2) S3_LN(2, 2);
+        else if (per_lane == 3) S3_LN(3, 2);
+        else S3_LN(4, 2);
+    } else if (per_lane <= 1) S3_LN(1, 1);
+    else if (per_lane == 2) S3_LN(2, 1);
+    else if (per_lane == 3) S3_LN(3, 1);
+    else if (per_lane == 4) S3_LN(4, 1);
+    else S3_LN(8, 1);
 #undef S3_LN
     return hipGetLastError();
 }
