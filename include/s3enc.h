@@ -310,6 +310,13 @@ int s3enc_debug_clock_sample(uint64_t* out3_device, void* stream);
  *                   knob — leaving CUs to a collective's channel kernels costs more than sharing them: profiles/r05_cu_contention.md);
  *   "conv0_nt":     1 (default) = the fp32 conv0 kernel writes its activation with non-temporal stores, 0 = plain stores;
  *   "ws_inplace":   1 (default) = post-LN layers run LayerNorm 1 and fc2 in place on one fp32 workspace buffer, 0 = two buffers;
+ *   "ln1_fold":     16-bit modes, post-LN layers: 1 (default) = LayerNorm 1 writes its 16-bit output and the rows' (mean, rstd) only and
+ *                   fc2's epilogue rebuilds the fp32 rows it adds from the row it normalised; 0 = LayerNorm 1 writes them; same bits;
+ *   "ln_rows":      rows per wave of the row LayerNorm: 1 (default), 2 = two rows' loads in flight (launches of >= 8192 rows); same
+ *                   bits; measured 2-3 % slower, kept for re-measurement;
+ *   "gn_lag_one_block": 1 (default) = the GroupNorm lag sums of the waveform come from one workgroup per (4096-frame chunk,
+ *                   utterance) over an LDS-staged window, 0 = the earlier k0-workgroups kernel; same bits
+ *                   (profiles/r06b_gn_stats.md);
  *   "gelu32":       S3ENC_F32 only: 1 = the one-transcendental erf-GELU every mode uses (default; csrc/common.h gelu_fast: as
  *                   close to an fp64 erf-GELU as 0.5 x (1 + erff(x / sqrt 2)) evaluated in fp32), 0 = libm erff — results
  *                   differ in the last bits. */

@@ -71,6 +71,11 @@ __device__ __forceinline__ void split8(const float4& x0, const float4& x1, uint4
     pair(x1.z, x1.w, hi.w, lo.w);
 }
 
+// One LayerNorm output element from the row's statistics: ((v - mu) * rs) * g + b with the last product fused — the ONE form both the
+// row LayerNorm (norm.hip) and a GEMM epilogue that rebuilds a LayerNorm output from its input row (gemm16.hip, GemmParams::res_ln_*)
+// evaluate, so that the two give the same bits.
+__device__ __forceinline__ float ln_affine(float v, float mu, float rs, float g, float b) { return __builtin_fmaf((v - mu) * rs, g, b); }
+
 // erf-GELU in fp32: nn.GELU() / F.gelu(x.float()) on the reference path.
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 

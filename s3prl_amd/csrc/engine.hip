@@ -733,7 +733,7 @@ int forward_body(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
     const bool featln = !c.no_feature_layer_norm;
     const bool ffn_tap = fo.selection == S3ENC_SEL_FFN_OUT;
     const long HW = std::max<long>(F, (long)NH * D);  // widest row of the FFN / prediction-head intermediate
-    void *actA, *actB, *tmp32, *feat32, *featT, *x32, *xpc, *xT, *qkv, *attn, *tmp1, *tmp2, *hbuf, *gate, *ffnbuf;
+    void *actA, *actB, *tmp32, *feat32, *featT, *x32, *xpc, *xT, *qkv, *attn, *tmp1, *tmp2, *hbuf, *gate, *ffnbuf, *lnst;
     for (int pass = 0; pass < 2; ++pass) {
         Bump wb(pass ? e->ws.p : nullptr);
         // conv0's output in the compute dtype; in the fp16x2 hybrid conv2, conv4, ... write fp32 rows back here: L[2] <= L[0] / 2
@@ -751,6 +751,7 @@ int forward_body(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
         attn = wb.take((size_t)M * D * (e->x2_attn_f32 ? 4 : es));
         tmp1 = wb.take((size_t)M * D * 4);
         tmp2 = wb.take((size_t)M * D * 4);
+        lnst = wb.take((size_t)M * sizeof(float2));  // (mean, rstd) per row: LayerNorm 1 -> fc2's epilogue (ln1_fold)
         hbuf = wb.take((size_t)M * HW * es);
         gate = gated ? wb.take((size_t)B * H * T * 4) : nullptr;
         ffnbuf = (ffn_tap && (fo.featurize || fo.out_dtype != F32)) ? wb.take((size_t)M * D * 4) : nullptr;
@@ -1076,11 +1077,37 @@ int forward_body(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
         }
         const float* ffn_res;
         const void* ffn_in;
+        // round 6 (second session): in the 16-bit modes a post-LN layer's LayerNorm 1 need not write its fp32 output — that tensor is only
+        // fc2's residual, and fc2's epilogue can rebuild it from the row it reads anyway and two numbers per row (GemmParams::res_ln_*;
+        // -49 MB of stores per layer at the reference batch).  Decided from fc2's shape class (gemm16_res_ln_ok), never from M
+        bool ln1_fold = false;
+        if (!prel && dt != F32 && !ffn_tap && tuning().ln1_fold) {
+            GemmParams q{};
+            q.A = hbuf;
+            q.lda = F;
+            q.W = Lw.w2.p;
+            q.W_x3 = Lw.w23.p;
+            q.bias = (const float*)Lw.b2.p;
+            q.M = (int)M;
+            q.N = D;
+            q.K = F;
+            q.batches = 1;
+            q.ldo = D;
+            q.residual = (const float*)tmp1;
+            q.out32 = (float*)tmp1;
+            ln1_fold = gemm16_res_ln_ok(dt, wsplit_of(e, q));
+        }
         if (prel) {  // b = LN2(y) feeds fc1; residual is y itself
             Prof pr(e, st, "layernorm:ln2", 0, gM * D * (4 + es));
             HIP_TRY(launch_layernorm(dt, (const float*)tmp1, (const float*)Lw.ln2g.p, (const float*)Lw.ln2b.p, M, D, 0,
                                      dt == F32 ? (float*)xT : nullptr, dt == F32 ? nullptr : xT, st));
             ffn_res = (const float*)tmp1;
+            ffn_in = xT;
+        } else if (ln1_fold) {  // 16-bit modes: LN1 writes the fc1 operand and the rows' (mean, rstd); fc2's epilogue rebuilds x1 = LN1(y)
+            Prof pr(e, st, "layernorm:ln1", 0, gM * D * (4 + es));
+            HIP_TRY(launch_layernorm(dt, (const float*)tmp1, (const float*)Lw.ln1g.p, (const float*)Lw.ln1b.p, M, D, 0,
+                                     nullptr, xT, st, LnAcc(), LnGate(), (float2*)lnst));
+            ffn_res = (const float*)tmp1;  // (y itself: fc2 normalises the rows it adds, then overwrites them in place)
             ffn_in = xT;
         } else {  // x1 = LN1(y): both the fc1 operand and the FFN residual
             Prof pr(e, st, "layernorm:ln1", 0, gM * D * (8 + (dt == F32 ? 0 : es)));
@@ -1146,6 +1173,11 @@ int forward_body(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
                 g.residual = ffn_res;
                 g.out32 = fc2_dst;
                 g.out16 = prel ? sink.slot16(si_next) : nullptr;
+                if (ln1_fold) {
+                    g.res_ln_stats = (const float2*)lnst;
+                    g.res_ln_g = (const float*)Lw.ln1g.p;
+                    g.res_ln_b = (const float*)Lw.ln1b.p;
+                }
                 Prof pr(e, st, "gemm:fc2", 2.0 * gM * D * F, (gM * F + (double)D * F) * es + gM * D * 8);
                 HIP_TRY(launch_gemm(dt, wsplit_of(e, g), st));
             }

@@ -333,6 +333,7 @@ hipError_t launch_gemm(int dtype, const GemmParams& p0, hipStream_t stream) {
     if (p.variant < 0) p.variant = tuning().gemm_variant;  // default 3: 64-byte stages + LDS-DMA (register staging for a ragged K)
     if (p.M <= 0 || p.N <= 0 || p.batches <= 0) return hipSuccess;
     if (dtype == F32 && p.act == 1 && tuning().gelu32 == 1) p.act = 2;  // fp32 products, the one-transcendental GELU
+    if (p.res_ln_stats && (dtype == F32 || !p.res_ln_g || !p.res_ln_b || !gemm16_res_ln_ok(dtype, p))) return hipErrorInvalidValue;
     if (p.wsplit) {
         if (dtype == F32) return hipErrorInvalidValue;
         if (!p.ldw) p.ldw = 2L * p.K;

@@ -541,7 +541,7 @@ __global__ __launch_bounds__(128 * WN, WPE) void gemm16_big_kernel(GemmParams p)
     // a tile with every row and column inside the product stores unconditionally: a fixed number of store instructions
     const bool full_tile = m0 + BM <= p.M && n0 + BN <= p.N;
     int n_stores = 0;
-    auto epilogue = [&](auto spec, auto act_c, auto res_c, auto o32_c, auto o16_c, auto full_c) {
+    auto epilogue = [&](auto spec, auto act_c, auto res_c, auto o32_c, auto o16_c, auto full_c, auto ln_c) {
         constexpr bool SPEC = decltype(spec)::value;
         constexpr bool FULL = decltype(full_c)::value;
         // residual epilogue (out_proj, fc2): the residual rows of a staging round are loaded one round AHEAD, before that round's
@@ -629,9 +629,20 @@ __global__ __launch_bounds__(128 * WN, WPE) void gemm16_big_kernel(GemmParams p)
             if (FULL || (m < p.M && n < p.N)) return *(const float4*)(p.residual + ob + (long)m * p.ldo + n);
             return make_float4(0.f, 0.f, 0.f, 0.f);
         };
+        // res_ln_*: the residual rows are the INPUT of a LayerNorm; its output is rebuilt here from the rows' (mean, rstd) — they ride
+        // with the residual prefetch — and the columns' gamma / beta (two float4 per staging round)
+        // (lane l keeps the statistics of row l & 31 of the current 32-row block — two registers, fetched one block ahead — and a pass
+        //  reads its row's pair from that lane by ds_bpermute: eight prefetched float2 per lane spilled the 256-row tile's epilogue)
+        constexpr bool RESLN = RESPF && decltype(ln_c)::value;
+        float2 rst_cur = make_float2(0.f, 1.f), rst_nxt = make_float2(0.f, 1.f);
+        auto st_load = [&](int i) -> float2 {
+            const int m = m0 + wr * WTM + i * 32 + l31;
+            return p.res_ln_stats[m < p.M ? m : p.M - 1];
+        };
         if constexpr (RESPF) {
 #pragma unroll
             for (int t = 0; t < NPASS; ++t) rsb[t] = res_load1(0, t);
+            if constexpr (RESLN) rst_nxt = st_load(0);
             do_pre();
         }
 #pragma unroll
@@ -641,6 +652,17 @@ __global__ __launch_bounds__(128 * WN, WPE) void gemm16_big_kernel(GemmParams p)
                 const int rd = i * NJB + jb;
                 const int n = n0 + wc * 64 + jb * SW + c4;
                 const bool n_ok = FULL || n < p.N;
+                float4 lg = make_float4(1.f, 1.f, 1.f, 1.f), lb = make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (RESLN) {
+                    if (n_ok) {
+                        lg = *(const float4*)(p.res_ln_g + n);
+                        lb = *(const float4*)(p.res_ln_b + n);
+                    }
+                    if (jb == 0) {
+                        rst_cur = rst_nxt;
+                        if (i + 1 < MI) rst_nxt = st_load(i + 1);
+                    }
+                }
 #pragma unroll
                 for (int jj = 0; jj < NJ; ++jj)
 #pragma unroll
@@ -662,6 +684,15 @@ __global__ __launch_bounds__(128 * WN, WPE) void gemm16_big_kernel(GemmParams p)
                             float4 rs;
                             if constexpr (RESPF) rs = rsb[t];
                             else rs = *(const float4*)(p.residual + o);
+                            if constexpr (RESLN) {  // the LayerNorm output of the stored row (norm.hip evaluates the same ln_affine)
+                                const int src = (t * RPS + lane / LPR) * 4;  // (byte address of the lane that holds this row's pair)
+                                const float mu = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(rst_cur.x)));
+                                const float rr = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(rst_cur.y)));
+                                rs.x = ln_affine(rs.x, mu, rr, lg.x, lb.x);
+                                rs.y = ln_affine(rs.y, mu, rr, lg.y, lb.y);
+                                rs.z = ln_affine(rs.z, mu, rr, lg.z, lb.z);
+                                rs.w = ln_affine(rs.w, mu, rr, lg.w, lb.w);
+                            }
                             v.x += rs.x; v.y += rs.y; v.z += rs.z; v.w += rs.w;
                         }
                         if (!SPEC && m >= limit) v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -687,16 +718,19 @@ __global__ __launch_bounds__(128 * WN, WPE) void gemm16_big_kernel(GemmParams p)
     const bool a = p.act != 0, r = p.residual != nullptr, w32 = p.out32 != nullptr, w16 = p.out16 != nullptr;
     // FULL instantiations exist only where their fixed store count is used (OVL, a following tile, no residual loads)
     const bool full = OVL && want_count && full_tile && !r && !p.row_limit && !S3_GPROBE(p, 16);
-    if (p.row_limit) epilogue(FF{}, FF{}, FF{}, FF{}, FF{}, FF{});                         // generic (proj: padded-frame zeroing)
+    if (p.row_limit) epilogue(FF{}, FF{}, FF{}, FF{}, FF{}, FF{}, FF{});                         // generic (proj: padded-frame zeroing)
     else if (a && !r && !w32 && w16) {                                                     // conv1-5, fc1
-        if constexpr (OVL) { if (full) { epilogue(TT{}, TT{}, FF{}, FF{}, TT{}, TT{}); return n_stores; } }
-        epilogue(TT{}, TT{}, FF{}, FF{}, TT{}, FF{});
+        if constexpr (OVL) { if (full) { epilogue(TT{}, TT{}, FF{}, FF{}, TT{}, TT{}, FF{}); return n_stores; } }
+        epilogue(TT{}, TT{}, FF{}, FF{}, TT{}, FF{}, FF{});
     } else if (!a && !r && !w32 && w16) {                                                  // q|k|v
-        if constexpr (OVL) { if (full) { epilogue(TT{}, FF{}, FF{}, FF{}, TT{}, TT{}); return n_stores; } }
-        epilogue(TT{}, FF{}, FF{}, FF{}, TT{}, FF{});
-    } else if (!a && r && w32 && !w16) epilogue(TT{}, FF{}, TT{}, TT{}, FF{}, FF{});       // out_proj, fc2
-    else if (a && !r && w32 && !w16) epilogue(TT{}, TT{}, FF{}, TT{}, FF{}, FF{});         // last conv (feeds the fp32 LayerNorm)
-    else epilogue(FF{}, FF{}, FF{}, FF{}, FF{}, FF{});
+        if constexpr (OVL) { if (full) { epilogue(TT{}, FF{}, FF{}, FF{}, TT{}, TT{}, FF{}); return n_stores; } }
+        epilogue(TT{}, FF{}, FF{}, FF{}, TT{}, FF{}, FF{});
+    } else if (!a && r && w32 && !w16) {                                                   // out_proj, fc2
+        if (p.res_ln_stats) epilogue(TT{}, FF{}, TT{}, TT{}, FF{}, FF{}, TT{});            // (fc2 of a post-LN layer: the residual rows are LayerNorm inputs)
+        else epilogue(TT{}, FF{}, TT{}, TT{}, FF{}, FF{}, FF{});
+    }
+    else if (a && !r && w32 && !w16) epilogue(TT{}, TT{}, FF{}, TT{}, FF{}, FF{}, FF{});         // last conv (feeds the fp32 LayerNorm)
+    else epilogue(FF{}, FF{}, FF{}, FF{}, FF{}, FF{}, FF{});
     return 0;
     }
     };
@@ -847,6 +881,14 @@ bool gemm16_big_eligible(int dtype, const GemmParams& p) {
     // no lower bound on M: loads clamp and stores mask ragged rows, and a batch of few frames must take the kernel (and with it
     // the k grouping per MFMA, i.e. the rounding) its rows would take inside a large batch
     return p.N >= 128;
+}
+
+// GemmParams::res_ln_*: only the specialised residual epilogue of gemm16_big_kernel rebuilds LayerNorm rows — the combination the
+// post-LN layers' fc2 has (fp32 output, no activation, no 16-bit copy, no row limit, one batch).  A property of the call's shape
+// class, never of M: the engine asks before it decides what LayerNorm 1 writes.
+bool gemm16_res_ln_ok(int dtype, const GemmParams& p) {
+    return gemm16_big_eligible(dtype, p) && p.residual && p.out32 && !p.out16 && !p.act && !p.row_limit && p.batches == 1 && p.o_bs == 0 &&
+           p.ldo == p.N;
 }
 
 bool gemm16_mx_eligible(int dtype, const GemmParams& p) {

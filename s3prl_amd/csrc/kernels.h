@@ -62,6 +62,8 @@ struct Tuning {
                            // >= 8192 rows; bit-identical by test).  MEASURED AND LEFT OFF (round 6, second session, same lease, HuBERT-base
                            // 32 x 10 s): LN1 + LN2 0.536 -> 0.551 ms per bf16 forward, 0.513 -> 0.529 fp32 — the kernel is at the memory
                            // side's rate (5.3-6.1 TB/s), not short of loads in flight
+    int ln1_fold = 1;      // engine.hip, post-LN layers in the 16-bit modes: 1 = LayerNorm 1 writes its 16-bit output and the rows' statistics only, fc2's
+                           // epilogue rebuilds the fp32 rows it adds (bit-identical to 0 = LayerNorm 1 writes them)
     int gn_lag_one_block = 1;  // frontend.hip: 1 = GroupNorm lag sums from ONE workgroup per (4096-frame chunk, utterance) over an LDS-staged
                            // window (bit-identical to the k0-workgroups form, 95.7 -> see profiles/r06b_gn_stats.md), 0 = the earlier kernel
     int comm_self_p2p = 0; // comm.hip, S3ENC_EXCHANGE_DIRECT: 1 = a rank's OWN block also travels as an ncclSend-to-self / ncclRecv-from-self
@@ -102,6 +104,13 @@ struct GemmParams {
     int act;                // 0 none, 1 erf-GELU
     const float* residual;  // fp32, indexed like out32; added after the activation
     const int* row_limit;   // per batch: rows >= row_limit[b] are written as 0
+    // round 6 (second session): the residual is NOT read as stored — `residual` holds the INPUT rows t of a LayerNorm and the epilogue
+    // adds LayerNorm(t) = ln_affine(t, mu, rs, gamma, beta) rebuilt from the row's statistics (res_ln_stats[m] = (mu, rs), written by
+    // launch_layernorm(..., stats_out)): the post-LN layers' LayerNorm 1 no longer writes its fp32 output (49 MB per layer at the
+    // reference batch), fc2 re-reads the row it normalised.  gemm16_big residual epilogue only (gemm16_res_ln_ok)
+    const float2* res_ln_stats = nullptr;
+    const float* res_ln_g = nullptr;
+    const float* res_ln_b = nullptr;
     float* out32;
     void* out16;
     long ldo, o_bs;
@@ -127,6 +136,7 @@ hipError_t launch_gemm_x3(const GemmParams& p, hipStream_t stream);
 void pack_x3(const float* w, long N, long K, std::vector<uint16_t>& out);  // host: fp32 (N, K) -> pair-packed bf16 hi / lo
 // gemm16.hip: large-tile LDS-DMA kernel for the 16-bit modes (tuning().gemm16_big)
 bool gemm16_big_eligible(int dtype, const GemmParams& p);
+bool gemm16_res_ln_ok(int dtype, const GemmParams& p);  // may this call carry GemmParams::res_ln_* ?
 hipError_t launch_gemm16_big(int dtype, const GemmParams& p, hipStream_t stream);
 // gemmt.hip: (256 | 192 | 128 | 64) x 128 tiles, several independent workgroups per CU; fp32 results bit-identical to
 // gemm.hip's kernel.  tuning().gemm32_big (fp32) / .gemm_x3_tile (S3ENC_F32X3 = dtype code 3 below: fp32 operands, the
@@ -191,7 +201,8 @@ struct LnGate {
 // act: 0 none, 1 erf-GELU of the mode (16-bit: common.h gelu_fast; fp32: the same unless tuning gelu32 = 0 -> libm erff),
 //      2 gelu_fast regardless of dtype and tuning
 hipError_t launch_layernorm(int dtype, const float* x, const float* gamma, const float* beta, long rows, int C, int act,
-                            float* out32, void* out16, hipStream_t s, const LnAcc& fa = LnAcc(), const LnGate& gt = LnGate());
+                            float* out32, void* out16, hipStream_t s, const LnAcc& fa = LnAcc(), const LnGate& gt = LnGate(),
+                            float2* stats_out = nullptr);  // stats_out[row] = (mean, 1 / sqrt(var + eps)) of the row
 // a state produced by a non-LayerNorm kernel: its 16-bit copy (out16, dtype BF16 / F16) and / or its Featurizer term
 hipError_t launch_emit_state(int dtype, const float* x, long rows, int C, void* out16, const LnAcc& fa, hipStream_t s);
 hipError_t launch_add(const float* a, const float* b, float* out, long n, hipStream_t s);  // out = a + b, n % 4 == 0

@@ -19,7 +19,7 @@ namespace {
 template <typename T, int NCH, int R>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, long rows, int C, int act,
-                                                        float* out32, void* out16, LnAcc fa, LnGate gt, int* status) {
+                                                        float* out32, void* out16, LnAcc fa, LnGate gt, int* status, float2* stats) {
     typedef typename Cvt<T>::store_t store_t;
     const long row0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
     if (row0 >= rows) return;
@@ -55,6 +55,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
     const float rs = rsqrtf(var + LN_EPS);
     // a non-finite element makes mu or var non-finite (inf - inf = NaN): one atomic on the rare path, nothing on the common one
     if (status && lane == 0 && !(fabsf(mu) <= 3.0e38f && var <= 3.0e38f)) atomicOr(status, 1);
+    if (stats && lane == 0) stats[row] = make_float2(mu, rs);
     if (fa.mode == 1) {  // the INPUT row is a state: acc (+)= w * x, or w * (x - mu) * rs with the statistics above
         const float a = fa.norm ? fa.w * rs : fa.w, c0 = fa.norm ? -mu * a : 0.f;
 #pragma unroll
@@ -91,8 +92,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
             if (ch < nch) {
                 const float4 g = *(const float4*)(gamma + 4 * ch);
                 const float4 bt = *(const float4*)(beta + 4 * ch);
-                const float y0 = (v[i].x - mu) * rs * g.x + bt.x, y1 = (v[i].y - mu) * rs * g.y + bt.y;
-                const float y2 = (v[i].z - mu) * rs * g.z + bt.z, y3 = (v[i].w - mu) * rs * g.w + bt.w;
+                const float y0 = ln_affine(v[i].x, mu, rs, g.x, bt.x), y1 = ln_affine(v[i].y, mu, rs, g.y, bt.y);
+                const float y2 = ln_affine(v[i].z, mu, rs, g.z, bt.z), y3 = ln_affine(v[i].w, mu, rs, g.w, bt.w);
                 sa = y0 * gwa[0] + y1 * gwa[1] + y2 * gwa[2] + y3 * gwa[3];
                 sb = y0 * gwb[0] + y1 * gwb[1] + y2 * gwb[2] + y3 * gwb[3];
             }
@@ -110,10 +111,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
         const float4 g = *(const float4*)(gamma + 4 * ch);
         const float4 bt = *(const float4*)(beta + 4 * ch);
         float4 y;
-        y.x = (v[i].x - mu) * rs * g.x + bt.x;
-        y.y = (v[i].y - mu) * rs * g.y + bt.y;
-        y.z = (v[i].z - mu) * rs * g.z + bt.z;
-        y.w = (v[i].w - mu) * rs * g.w + bt.w;
+        y.x = ln_affine(v[i].x, mu, rs, g.x, bt.x);
+        y.y = ln_affine(v[i].y, mu, rs, g.y, bt.y);
+        y.z = ln_affine(v[i].z, mu, rs, g.z, bt.z);
+        y.w = ln_affine(v[i].w, mu, rs, g.w, bt.w);
         if (act) {
             if (sizeof(typename Cvt<T>::store_t) == 2 || act == 2) gelu4<true>(y.x, y.y, y.z, y.w);
             else gelu4<false>(y.x, y.y, y.z, y.w);
@@ -245,11 +246,11 @@ __global__ __launch_bounds__(256) void add_kernel(const float4* a, const float4*
 
 template <typename T>
 hipError_t ln_dispatch(const float* x, const float* gamma, const float* beta, long rows, int C, int act, float* out32,
-                       void* out16, const LnAcc& fa, const LnGate& gt, hipStream_t s) {
+                       void* out16, const LnAcc& fa, const LnGate& gt, hipStream_t s, float2* stats_out) {
     const int per_lane = ((C >> 2) + 63) / 64;
     const int R = (tuning().ln_rows == 2 && per_lane <= 4 && rows >= 8192) ? 2 : 1;  // (two rows per wave only where the grid still fills the chip)
     dim3 grid((unsigned)((rows + 4 * R - 1) / (4 * R))), block(256);
-#define S3_LN(N, RR) hipLaunchKernelGGL((layernorm_kernel<T, N, RR>), grid, block, 0, s, x, gamma, beta, rows, C, act, out32, out16, fa, gt, t_status)
+#define S3_LN(N, RR) hipLaunchKernelGGL((layernorm_kernel<T, N, RR>), grid, block, 0, s, x, gamma, beta, rows, C, act, out32, out16, fa, gt, t_status, stats_out)
     if (R == 2) {
         if (per_lane <= 1) S3_LN(1, 2);
         else if (per_lane == 2) S3_LN(2, 2);
@@ -267,15 +268,15 @@ hipError_t ln_dispatch(const float* x, const float* gamma, const float* beta, lo
 }  // namespace
 
 hipError_t launch_layernorm(int dtype, const float* x, const float* gamma, const float* beta, long rows, int C, int act,
-                            float* out32, void* out16, hipStream_t s, const LnAcc& fa, const LnGate& gt) {
+                            float* out32, void* out16, hipStream_t s, const LnAcc& fa, const LnGate& gt, float2* stats_out) {
     if (rows <= 0) return hipSuccess;
     if ((C & 3) || C > 2048) return hipErrorInvalidValue;
     if (gt.gate && (gt.H * 64 != C || gt.T <= 0 || act)) return hipErrorInvalidValue;
     if (dtype == F32 && act == 1 && tuning().gelu32 == 1) act = 2;
     switch (dtype) {
-        case F32: return ln_dispatch<float>(x, gamma, beta, rows, C, act, out32, out16, fa, gt, s);
-        case BF16: return ln_dispatch<bf16_tag>(x, gamma, beta, rows, C, act, out32, out16, fa, gt, s);
-        case F16: return ln_dispatch<f16_tag>(x, gamma, beta, rows, C, act, out32, out16, fa, gt, s);
+        case F32: return ln_dispatch<float>(x, gamma, beta, rows, C, act, out32, out16, fa, gt, s, stats_out);
+        case BF16: return ln_dispatch<bf16_tag>(x, gamma, beta, rows, C, act, out32, out16, fa, gt, s, stats_out);
+        case F16: return ln_dispatch<f16_tag>(x, gamma, beta, rows, C, act, out32, out16, fa, gt, s, stats_out);
     }
     return hipErrorInvalidValue;
 }

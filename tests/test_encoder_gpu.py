@@ -584,6 +584,31 @@ def test_fp16x2_mx_second_term_keeps_the_mode_inside_its_tolerance(name, golden_
     assert errs[14] < errs[0] + 1e-4, f"{name}: MX second term {errs[14]:.3e} vs two fp16 terms {errs[0]:.3e}"
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp16", "fp16x2"])
+@pytest.mark.parametrize("name", ["hubert_base_pl", "wav2vec2_base_pl", "wavlm_base_plus_pseudo", "data2vec_base_pseudo", "hubert_large_pl",
+                                  "tiny_hubert_pad"])
+def test_layernorm1_fold_into_fc2_is_bit_identical(name, dtype, golden_loader):
+    """Round 6 (second session), tuning key `ln1_fold` (default 1): in the 16-bit modes a post-LN layer's LayerNorm 1 writes its 16-bit
+    output and the rows' (mean, rstd) only; fc2's residual epilogue reads the LayerNorm INPUT row and rebuilds the fp32 output it adds
+    (one shared `ln_affine`).  Every hidden state must equal the unfolded forward bit for bit — ragged batches, every fc2 kernel variant
+    (two fp16 terms, the MX second term, bf16), a pre-LN model (the key selects nothing there) and a tiny one (fc2 off the big kernel)."""
+    from s3prl_amd import _lib
+
+    meta, cfg, weights, wavs, golden, _ = golden_loader(name)
+    lib = _lib.load()
+    outs = {}
+    try:
+        for on in (1, 0):
+            _lib.check(lib.s3enc_set_tuning(b"ln1_fold", on))
+            enc = _encoder(cfg, weights, dtype=dtype)
+            outs[on] = _run(enc, wavs)
+            enc.close()
+    finally:
+        _lib.check(lib.s3enc_set_tuning(b"ln1_fold", 1))
+    assert np.isfinite(outs[1]).all()
+    assert np.array_equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("name", ["wavlm_large_s1_pl", "hubert_base_s1_pl", "data2vec_base_s2_pl", "tiny_hubert_large_pad"])
 def test_fp16x2_conv1_on_fp32_rows_option(name, golden_loader):
     """Round 6, tuning key `fp16x2_conv1_f32` (read at s3enc_create): conv0 writes fp32 and conv1 takes the three-term GEMM like
