@@ -312,6 +312,7 @@ int s3enc_debug_clock_sample(uint64_t* out3_device, void* stream);
  *   "ws_inplace":   1 (default) = post-LN layers run LayerNorm 1 and fc2 in place on one fp32 workspace buffer, 0 = two buffers;
  *   "ln1_fold":     16-bit modes, post-LN layers: 1 (default) = LayerNorm 1 writes its 16-bit output and the rows' (mean, rstd) only and
  *                   fc2's epilogue rebuilds the fp32 rows it adds from the row it normalised; 0 = LayerNorm 1 writes them; same bits;
+ *   "ln_preload":   1 (default) = the row LayerNorm fetches gamma / beta together with the row instead of behind the reductions; same bits;
  *   "ln_rows":      rows per wave of the row LayerNorm: 1 (default), 2 = two rows' loads in flight (launches of >= 8192 rows); same
  *                   bits; measured 2-3 % slower, kept for re-measurement;
  *   "gn_lag_one_block": 1 (default) = the GroupNorm lag sums of the waveform come from one workgroup per (4096-frame chunk,

@@ -62,6 +62,7 @@ struct Tuning {
                            // >= 8192 rows; bit-identical by test).  MEASURED AND LEFT OFF (round 6, second session, same lease, HuBERT-base
                            // 32 x 10 s): LN1 + LN2 0.536 -> 0.551 ms per bf16 forward, 0.513 -> 0.529 fp32 — the kernel is at the memory
                            // side's rate (5.3-6.1 TB/s), not short of loads in flight
+    int ln_preload = 1;    // norm.hip: 1 = a wave fetches its gamma / beta chunks together with its row instead of behind the two reductions
     int ln1_fold = 1;      // engine.hip, post-LN layers in the 16-bit modes: 1 = LayerNorm 1 writes its 16-bit output and the rows' statistics only, fc2's
                            // epilogue rebuilds the fp32 rows it adds (bit-identical to 0 = LayerNorm 1 writes them)
     int gn_lag_one_block = 1;  // frontend.hip: 1 = GroupNorm lag sums from ONE workgroup per (4096-frame chunk, utterance) over an LDS-staged

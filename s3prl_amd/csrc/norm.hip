@@ -16,7 +16,9 @@ namespace {
 // 3 KB in flight per wave, ~6 MB per chip, 5.3-6.1 TB/s; R = 2 issues both rows' loads before the first reduction (same per-row
 // arithmetic in the same order: bit-identical; an in-place call still reads every row it owns before it writes one).  Measured:
 // 2-3 % SLOWER (tuning key ln_rows, default 1) — the kernel is not short of loads in flight.
-template <typename T, int NCH, int R>
+// PLAIN: no Featurizer term, no WavLM gate — the LayerNorms of a default forward: those paths compiled out (102 -> 52-64 registers: eight
+// waves per SIMD instead of four)
+template <typename T, int NCH, int R, bool PRE, bool PLAIN>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, long rows, int C, int act,
                                                         float* out32, void* out16, LnAcc fa, LnGate gt, int* status, float2* stats) {
@@ -27,6 +29,21 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
     const int nch = C >> 2;
     float4 vv[R][NCH];
     float ss[R];
+    // gamma / beta ride with the row loads (tuning key ln_preload): fetched where they are used they are a SECOND memory round trip on every
+    // wave's critical path, behind both reductions
+    float4 gq[NCH], bq[NCH];
+    const bool pre = PRE;
+    const bool has_gate = PLAIN ? false : gt.gate != nullptr;
+    const int fa_mode = PLAIN ? 0 : fa.mode;
+    const int act_ = act;
+    if (pre) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int ch = lane + 64 * i;
+            gq[i] = ch < nch ? *(const float4*)(gamma + 4 * ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+            bq[i] = ch < nch ? *(const float4*)(beta + 4 * ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const long row = row0 + r < rows ? row0 + r : rows - 1;  // (a row past the end re-reads the last one and is not processed)
@@ -56,7 +73,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
     // a non-finite element makes mu or var non-finite (inf - inf = NaN): one atomic on the rare path, nothing on the common one
     if (status && lane == 0 && !(fabsf(mu) <= 3.0e38f && var <= 3.0e38f)) atomicOr(status, 1);
     if (stats && lane == 0) stats[row] = make_float2(mu, rs);
-    if (fa.mode == 1) {  // the INPUT row is a state: acc (+)= w * x, or w * (x - mu) * rs with the statistics above
+    if (fa_mode == 1) {  // the INPUT row is a state: acc (+)= w * x, or w * (x - mu) * rs with the statistics above
         const float a = fa.norm ? fa.w * rs : fa.w, c0 = fa.norm ? -mu * a : 0.f;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
@@ -73,7 +90,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
     }
     // WavLM gate of the OUTPUT row: this lane's 4 dims of its head (chunk ch covers dims 4ch..4ch+3 of head ch >> 4)
     float gwa[4] = {0.f, 0.f, 0.f, 0.f}, gwb[4] = {0.f, 0.f, 0.f, 0.f}, gba = 0.f, gbb = 0.f;
-    if (gt.gate) {
+    if (has_gate) {
         const int k4 = (lane & 15) * 4;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -87,11 +104,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int ch = lane + 64 * i;
-        if (gt.gate) {  // wave-uniform; every lane takes part in the row reduction, lanes past the row contribute 0
+        if (has_gate) {  // wave-uniform; every lane takes part in the row reduction, lanes past the row contribute 0
             float sa = 0.f, sb = 0.f;
             if (ch < nch) {
-                const float4 g = *(const float4*)(gamma + 4 * ch);
-                const float4 bt = *(const float4*)(beta + 4 * ch);
+                const float4 g = pre ? gq[i] : *(const float4*)(gamma + 4 * ch);
+                const float4 bt = pre ? bq[i] : *(const float4*)(beta + 4 * ch);
                 const float y0 = ln_affine(v[i].x, mu, rs, g.x, bt.x), y1 = ln_affine(v[i].y, mu, rs, g.y, bt.y);
                 const float y2 = ln_affine(v[i].z, mu, rs, g.z, bt.z), y3 = ln_affine(v[i].w, mu, rs, g.w, bt.w);
                 sa = y0 * gwa[0] + y1 * gwa[1] + y2 * gwa[2] + y3 * gwa[3];
@@ -108,15 +125,15 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
             }
         }
         if (ch >= nch) continue;
-        const float4 g = *(const float4*)(gamma + 4 * ch);
-        const float4 bt = *(const float4*)(beta + 4 * ch);
+        const float4 g = pre ? gq[i] : *(const float4*)(gamma + 4 * ch);
+        const float4 bt = pre ? bq[i] : *(const float4*)(beta + 4 * ch);
         float4 y;
         y.x = ln_affine(v[i].x, mu, rs, g.x, bt.x);
         y.y = ln_affine(v[i].y, mu, rs, g.y, bt.y);
         y.z = ln_affine(v[i].z, mu, rs, g.z, bt.z);
         y.w = ln_affine(v[i].w, mu, rs, g.w, bt.w);
-        if (act) {
-            if (sizeof(typename Cvt<T>::store_t) == 2 || act == 2) gelu4<true>(y.x, y.y, y.z, y.w);
+        if (act_) {
+            if (sizeof(typename Cvt<T>::store_t) == 2 || act_ == 2) gelu4<true>(y.x, y.y, y.z, y.w);
             else gelu4<false>(y.x, y.y, y.z, y.w);
         }
         if (out32) *(float4*)(out32 + row * C + 4 * ch) = y;
@@ -132,12 +149,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
                 *(ushort4*)((u16*)out16 + row * C + 4 * ch) = h;
             }
         }
-        if (fa.mode == 2) {  // keep y in the registers of x for the accumulate pass below
+        if (fa_mode == 2) {  // keep y in the registers of x for the accumulate pass below
             v[i] = y;
             ys += (y.x + y.y) + (y.z + y.w);
         }
     }
-    if (fa.mode == 2) {  // the OUTPUT row is a state
+    if (fa_mode == 2) {  // the OUTPUT row is a state
         float a = fa.w, c0 = 0.f;
         if (fa.norm) {
             const float ym = wave_sum(ys) * invC;
@@ -250,7 +267,17 @@ hipError_t ln_dispatch(const float* x, const float* gamma, const float* beta, lo
     const int per_lane = ((C >> 2) + 63) / 64;
     const int R = (tuning().ln_rows == 2 && per_lane <= 4 && rows >= 8192) ? 2 : 1;  // (two rows per wave only where the grid still fills the chip)
     dim3 grid((unsigned)((rows + 4 * R - 1) / (4 * R))), block(256);
-#define S3_LN(N, RR) hipLaunchKernelGGL((layernorm_kernel<T, N, RR>), grid, block, 0, s, x, gamma, beta, rows, C, act, out32, out16, fa, gt, t_status, stats_out)
+    const bool plain = !fa.mode && !gt.gate;
+#define S3_LN2(N, RR, PRE_, PL_) hipLaunchKernelGGL((layernorm_kernel<T, N, RR, PRE_, PL_>), grid, block, 0, s, x, gamma, beta, rows, C, act, out32, out16, fa, gt, t_status, stats_out)
+#define S3_LN(N, RR)                                        \
+    do {                                                     \
+        if (tuning().ln_preload && (N) <= 4) {               \
+            if (plain) S3_LN2(N, RR, true, true);            \
+            else S3_LN2(N, RR, true, false);                 \
+        } else {                                             \
+            S3_LN2(N, RR, false, false);                     \
+        }                                                    \
+    } while (0)
     if (R == 2) {
         if (per_lane <= 1) S3_LN(1, 2);
         else if (per_lane == 2) S3_LN(2, 2);
@@ -262,6 +289,7 @@ hipError_t ln_dispatch(const float* x, const float* gamma, const float* beta, lo
     else if (per_lane == 4) S3_LN(4, 1);
     else S3_LN(8, 1);
 #undef S3_LN
+#undef S3_LN2
     return hipGetLastError();
 }
 
