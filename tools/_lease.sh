@@ -1,16 +1,11 @@
 set -u
-mkdir -p gpurun_out/r06b
-( timeout 900 python -m pytest tests/test_ops_gpu.py tests/test_encoder_gpu.py -m gpu -q -x -k "layernorm or fold or hub_expert" 2>&1 | grep -E "passed|failed|error" | tail -3 )
-Q="--no-cpu-baseline --no-other-modes --no-parity"
-run() { # name, args
-  python bench.py $Q $2 > gpurun_out/r06b/bench_$1.json 2>/dev/null
-  python - <<PY
-import json
-x=json.loads(open('gpurun_out/r06b/bench_$1.json').read().strip().splitlines()[-1]); k=x['kernels_ms_per_step']
-print('$1', x['ms_per_step'], x['clock_ghz'], 'ln1', k.get('layernorm:ln1'), 'ln2', k.get('layernorm:ln2'), 'conv', k.get('layernorm:conv'))
-PY
-}
-for t in 1 1; do run bf16_pre$t "--dtype bf16 --steps 200 --warmup 10 --tune ln_preload=$t"; done
-for t in 1 1; do run fp32_pre$t "--steps 50 --warmup 5 --tune ln_preload=$t"; done
-for t in 1; do run hl_bf16_pre$t "--model hubert_large --dtype bf16 --steps 60 --warmup 5 --tune ln_preload=$t"; done
-for t in 1 2; do run bf16_plain_rows$t "--dtype bf16 --steps 200 --warmup 10 --tune ln_rows=$t"; done
+mkdir -p gpurun_out/r06
+export TMPDIR=/tmp
+( time python -m pytest tests -m gpu -q -x > gpurun_out/r06/gputests_full_raw.log 2>&1 ) 2> gpurun_out/r06/gputests_time.log
+{ grep -E "passed|failed|error" gpurun_out/r06/gputests_full_raw.log | tail -3; cat gpurun_out/r06/gputests_time.log; } > gpurun_out/r06/gputests_final.log
+cat gpurun_out/r06/gputests_final.log
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+( time bash tools/round_profiles.sh r06 ) 2>&1 | tail -5
+python tools/parity_seeds.py > gpurun_out/r06/parity_seeds.md 2> gpurun_out/r06/parity_seeds.err
+tail -12 gpurun_out/r06/parity_seeds.md
+cut -c1-300 gpurun_out/r06/bench_fp32.json

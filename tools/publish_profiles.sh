@@ -15,7 +15,7 @@ for f in $src/kernel_stats_*.md; do
     cat $f; } > profiles/${tag}_kernel_stats_$name.md
 done
 for f in $src/pmc_*.md; do [ -s $f ] && cp $f profiles/${tag}_$(basename $f); done
-for f in gemm32_lab_fp32 gemm32_lab_x3 attn_lab gemm16_lab gemm16_lab_persistent gemm16_lab_modes gemm16_lab_modes_fp16x2 gemm16_lab_shared_panels parity; do [ -s $src/$f.md ] && cp $src/$f.md profiles/${tag}_$f.md; done
+for f in gemm32_lab_fp32 gemm32_lab_x3 attn_lab attn_lab_product gemm16_lab gemm16_lab_persistent gemm16_lab_modes gemm16_lab_modes_fp16x2 gemm16_lab_shared_panels parity; do [ -s $src/$f.md ] && cp $src/$f.md profiles/${tag}_$f.md; done
 [ -s $src/traffic.json ] && cp $src/traffic.json profiles/traffic.json
 # stamp the records measured on THIS tree's kernels with the commit they belong to (the GPU box has no .git; bench.py matches on
 # csrc_sha16 and quotes the commit)

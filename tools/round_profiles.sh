@@ -56,11 +56,12 @@ for d in fp32x3 fp32; do
   python bench.py --model wavlm_large --dtype $d --secs 15 --mixed $Q --steps 8 --warmup 1 > $out/bench_cfg4_wavlm_large_mixed_$d.json 2>/dev/null
 done
 # 4. micro labs (standalone binaries, seconds each)
-for b in gemm32_lab attn_lab gemm16_lab gemm16_loop_probe mx_probe; do [ -x tools/micro/$b ] || echo "tools/micro/$b is not built" >&2; done
+for b in gemm32_lab attn_lab attn_lab_product attn_lab_x0 gemm16_lab gemm16_loop_probe mx_probe; do [ -x tools/micro/$b ] || echo "tools/micro/$b is not built" >&2; done
 tools/micro/gemm16_lab cmp 7 8 9 10 > $out/gemm16_lab_modes.md 2>&1        # persistent loop / + store overlap / row-per-lane epilogue / both
 tools/micro/gemm16_lab cmpx 7 9 1007 > $out/gemm16_lab_modes_fp16x2.md 2>&1   # (1007: the MX second weight term, forced on every shape)
 tools/micro/gemm16_lab cmp8 7 > $out/gemm16_lab_shared_panels.md 2>&1       # every operand L2-resident: what the memory side costs
 tools/micro/attn_lab > $out/attn_lab.md 2>&1
+{ echo '## the kernels of the library (no probes compiled in)'; QUICK=1 SKIP_F32=1 tools/micro/attn_lab_product; echo; echo '## S3_ATTN_EXP = 0 (the kernels before the second session of round 6)'; QUICK=1 SKIP_F32=1 tools/micro/attn_lab_x0; } > $out/attn_lab_product.md 2>&1
 tools/micro/mx_probe > $out/mx_probe.md 2>&1
 # 5. parity of every mode against the reference's own outputs (synthetic and pretrained-like statistics)
 python tools/parity_table.py > $out/parity.md 2> $out/parity.err
