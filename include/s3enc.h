@@ -266,7 +266,12 @@ typedef struct s3enc_profile_entry {
 int s3enc_profile_read(s3enc_handle h, s3enc_profile_entry* entries, int32_t max_entries, int32_t* n_entries);
 
 /* Copy an intermediate of the LAST forward to the host as fp32 (test hook): the last three conv layers
- * ("conv4".."conv6" for the 7-layer stack), "feat_ln", "proj", "posconv", "qkv0", "attn0".  Synchronises. */
+ * ("conv4".."conv6" for the 7-layer stack), "feat_ln", "proj", "posconv", "qkv0", "attn0" ("qkv0" / "attn0" name the buffers: after a
+ * whole forward they hold the LAST layer's contents).  Synchronises.
+ * Diagnostic (tools/two_stream_probe.py --taps): with the environment variable S3ENC_DEBUG_STOP = k set when the library loads, every
+ * forward ends behind stage k — 1 + i: conv layer i, 20: the feature LayerNorm, 21: post_extract_proj, 22: the positional conv, 30 .. 34:
+ * layer 0's q|k|v / attention / out_proj / LayerNorm / fc1, 40 + l: in front of layer l — writes NO states, and keeps "conv0" .. as taps
+ * too (a conv tap is whole only for the last two conv layers that ran: the stack ping-pongs between two buffers). */
 int s3enc_debug_tap(s3enc_handle h, const char* name, float* host_out, int64_t max_elems, int64_t* n_elems);
 /* Measurement hook (no reference counterpart): `workgroups` x `threads` idle threads that hold their CU slots for `milliseconds` on
  * `stream` — a stand-in for a collective's channel kernels running beside the encoder (bench.py --steal-cus). */
@@ -298,6 +303,13 @@ int s3enc_debug_clock_sample(uint64_t* out3_device, void* stream);
  *                   differ at the 1e-5 ... 1e-4 level (profiles/r05_mx_second_term.md);
  *                   The mask is read at s3enc_create: only the kinds it names get an image (narrowing it on a live handle works,
  *                   widening needs a new handle);
+ *   "forward_chain": 1 (default) = a forward of a 16-bit / split-precision handle (S3ENC_BF16, S3ENC_F16, S3ENC_F16X2, S3ENC_F32X3) starts, on the
+ *                   device, behind the previous such forward of ANY handle of the process on that device (hipStreamWaitEvent on one event per
+ *                   device; no host wait; with one handle on one stream it adds nothing to stream order).  Forwards of several handles
+ *                   overlapping on four or more streams were measured NOT bit-stable in those modes — rare rows a few 16-bit ulps off, never
+ *                   with two streams, never in S3ENC_F32, no kernel alone reproduces it (profiles/r06c_concurrent_forwards.md) — so a
+ *                   serving process that keeps one encoder per model or per worker thread gets every utterance's own bits by default.
+ *                   0 = such forwards may overlap (small batches then fill the chip together: four 8 x 10 s forwards 12.1 -> 8.5 ms);
  *   "comm_self_p2p": S3ENC_EXCHANGE_DIRECT test hook: 1 = a rank's own block travels as an ncclSend-to-self / ncclRecv-from-self pair
  *                   inside the state's group instead of a device copy (how the all-pairs code executes on a one-GPU box); default 0;
  *   "fp16x2_conv1_f32": S3ENC_F16X2, read at s3enc_create: 1 = conv0 writes fp32 activations and conv1 reads them through the three-term

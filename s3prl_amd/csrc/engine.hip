@@ -595,14 +595,53 @@ struct Sink {
 int forward_body(s3enc_handle e, const float* const* wav_ptrs_host, const int64_t* lengths, int32_t B, int64_t n_max_in,
                  const FwdOpts& fo, void* out, int64_t layer_stride, hipStream_t st);
 
+// ---- forward chain: one event per device, re-recorded behind every forward; the next forward (any handle, any stream) waits for it on
+// the device.  hipStreamWaitEvent captures the record that is current when it is called, so re-using one event is safe; a stream that
+// waits for an event recorded on itself waits for nothing new.  Host cost: two runtime calls per forward under one mutex.
+namespace {
+struct ForwardChain {
+    std::mutex mu;
+    hipEvent_t ev[64] = {};
+    bool recorded[64] = {};
+};
+ForwardChain& forward_chain() {
+    static ForwardChain* c = new ForwardChain();  // (never destroyed: events must not outlive the runtime at process exit)
+    return *c;
+}
+hipError_t forward_chain_wait(int dev, hipStream_t st) {
+    if (dev < 0 || dev >= 64) return hipSuccess;
+    ForwardChain& c = forward_chain();
+    std::lock_guard<std::mutex> lock(c.mu);
+    if (!c.recorded[dev]) return hipSuccess;
+    return hipStreamWaitEvent(st, c.ev[dev], 0);
+}
+hipError_t forward_chain_record(int dev, hipStream_t st) {
+    if (dev < 0 || dev >= 64) return hipSuccess;
+    ForwardChain& c = forward_chain();
+    std::lock_guard<std::mutex> lock(c.mu);
+    if (!c.ev[dev]) {
+        hipError_t e = hipEventCreateWithFlags(&c.ev[dev], hipEventDisableTiming);
+        if (e != hipSuccess) return e;
+    }
+    hipError_t e = hipEventRecord(c.ev[dev], st);
+    if (e == hipSuccess) c.recorded[dev] = true;
+    return e;
+}
+}  // namespace
+
 // The forward proper runs with the handle's tuning and status word current for this thread.  The word is cleared in front of
 // it and copied to the next pinned slot behind it, with an event, so that s3enc_forward_status never has to touch the device.
 int forward_impl(s3enc_handle e, const float* const* wav_ptrs_host, const int64_t* lengths, int32_t B, int64_t n_max_in,
                  const FwdOpts& fo, void* out, int64_t layer_stride, hipStream_t st) {
     TuningScope tuning_scope(e->has_tuning ? &e->tun : nullptr);
     StatusScope status_scope((int*)e->status_dev.p);
+    // forward chain (tuning key forward_chain, kernels.h): this forward starts behind the previous forward of any handle on this device
+    // (exact fp32 — the tile kernel waits vmcnt(0) for every buffer_load ... lds — stayed bit-stable in every concurrent run and is left free to overlap)
+    const bool chain = tuning().forward_chain != 0 && (e->dtype != F32 || e->x3);
+    if (chain) HIP_TRY(forward_chain_wait(e->device, st));
     HIP_TRY(hipMemsetAsync(e->status_dev.p, 0, sizeof(int), st));
     const int rc = forward_body(e, wav_ptrs_host, lengths, B, n_max_in, fo, out, layer_stride, st);
+    if (chain) HIP_TRY(forward_chain_record(e->device, st));  // (also behind a failed forward: whatever it enqueued is in the stream)
     if (rc == 0) {
         const int slot = e->status_next;
         if (e->status_busy[slot]) {  // STATUS_RING forwards ago: finished long since unless the host ran far ahead
@@ -623,6 +662,7 @@ int forward_body(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
     const s3enc_config& c = e->cfg;
     const int C = c.conv_dim, D = c.embed_dim, F = c.ffn_dim, H = c.heads, NL = c.encoder_layers;
     const int dt = e->dtype, es = e->es;
+    static const int dbg_stop = getenv("S3ENC_DEBUG_STOP") ? atoi(getenv("S3ENC_DEBUG_STOP")) : 0;
     const bool dist = c.family == S3ENC_DISTILLER;
     const bool mr = c.family == S3ENC_MULTIRES;
     const int NH = dist ? c.pred_heads : 0;
@@ -805,6 +845,9 @@ int forward_body(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
         p.nt = tuning().conv0_nt;
         Prof pr(e, st, "conv0", 2.0 * B * L[0] * C * p.k0, 4.0 * B * n_max + (double)B * L[0] * C * (c0f32 ? 4 : es));
         HIP_TRY(launch_conv0(c0f32 ? (int)F32 : dt, p, st));
+        // (diagnostic, tools/two_stream_probe.py --taps: S3ENC_DEBUG_STOP = k ends the forward behind conv(k - 1) and keeps its output as a tap)
+        if (dbg_stop) e->taps["conv0"] = {actA, (long)B * L[0] * C, c0f32 ? (int)F32 : dt};
+        if (dbg_stop == 1) return 0;
     }
     // conv1..: implicit GEMM on channel-last activations.  The last one feeds LayerNorm(C) in fp32, or — without that
     // norm (DistilHuBERT) — post_extract_proj directly, in the compute dtype.
@@ -861,7 +904,8 @@ int forward_body(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
         }
         char tn[16];
         snprintf(tn, sizeof(tn), "conv%d", i);
-        if (i >= c.n_conv - 3) e->taps[tn] = {dst, (long)B * L[i] * C, f32out ? (int)F32 : dt};  // earlier ones get overwritten
+        if (i >= c.n_conv - 3 || dbg_stop) e->taps[tn] = {dst, (long)B * L[i] * C, f32out ? (int)F32 : dt};  // earlier ones get overwritten
+        if (dbg_stop == 1 + i) return 0;
         cur = dst;
     }
     // LayerNorm(C) -> post_extract_proj (+ zero padded frames)
@@ -871,6 +915,7 @@ int forward_body(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
         HIP_TRY(launch_layernorm(dt, (const float*)feat32, (const float*)e->fln_g.p, (const float*)e->fln_b.p, M, C, 0,
                                  proj32 ? (float*)featT : nullptr, proj32 ? nullptr : featT, st));
         e->taps["feat_ln"] = {featT, M * C, proj32 ? (int)F32 : dt};
+        if (dbg_stop == 20) return 0;
     }
     const int si_proj = dist ? 0 : -1;  // DistilHuBERT: hidden_states[0] = feat_final, padded frames zeroed in place
     float* xproj = sink.slot32(si_proj) ? sink.slot32(si_proj) : (float*)x32;
@@ -901,6 +946,7 @@ int forward_body(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
             }
         }
         e->taps["proj"] = {xproj, M * D, F32};
+        if (dbg_stop == 21) return 0;
         HIP_TRY(sink.emit(si_proj, xproj, false));
         HIP_TRY(sink.done(si_proj));
     }
@@ -960,6 +1006,7 @@ int forward_body(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
             HIP_TRY(run_conv(p));
         }
         e->taps["posconv"] = {p.out, M * D, F32};
+        if (dbg_stop == 22) return 0;
         if (prel) {
             x_cur = pc_out;
             if (sink.mode == 1) HIP_TRY(sink.emit(si0, pc_out));  // featurize: ln1 of layer 0 adds this state's term
@@ -1004,6 +1051,7 @@ int forward_body(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
     int si_cur = si_hidden(0);  // state index of x_cur (pre-LN featurize: its term is added by the LayerNorm that reads it)
     for (int l = 0; l < NL; ++l) {
         LayerW& Lw = e->layers[l];
+        if (dbg_stop == 40 + l) return 0;  // (before layer l)
         const bool lastl = l == NL - 1;
         const void* a_in;       // operand of the q|k|v GEMM
         const float* gate_src;  // WavLM: the attention module's input
@@ -1036,6 +1084,7 @@ int forward_body(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
             Prof pr(e, st, "gemm:qkv", 2.0 * gM * 3 * D * D, (gM * D + 3.0 * D * D + gM * 3 * D) * es);
             HIP_TRY(launch_gemm(dt, wsplit_of(e, g), st));
             if (l == 0) e->taps["qkv0"] = {qkv, M * 3 * D, dt};
+            if (dbg_stop == 30 && l == 0) return 0;
         }
         {
             AttnParams a{};
@@ -1052,6 +1101,7 @@ int forward_body(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
             Prof pr(e, st, "attention", 4.0 * B * H * (double)T * T * 64, gM * 4 * D * es);
             HIP_TRY(launch_attention(e->x3 ? 3 : dt, a, st));
             if (l == 0) e->taps["attn0"] = {attn, M * D, e->x2_attn_f32 ? (int)F32 : dt};
+            if (dbg_stop == 31 && l == 0) return 0;
         }
         {   // out_proj + bias + residual
             GemmParams g{};
@@ -1077,6 +1127,7 @@ int forward_body(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
         }
         const float* ffn_res;
         const void* ffn_in;
+        if (dbg_stop == 32 && l == 0) return 0;  // (behind out_proj)
         // round 6 (second session): in the 16-bit modes a post-LN layer's LayerNorm 1 need not write its fp32 output — that tensor is only
         // fc2's residual, and fc2's epilogue can rebuild it from the row it reads anyway and two numbers per row (GemmParams::res_ln_*;
         // -49 MB of stores per layer at the reference batch).  Decided from fc2's shape class (gemm16_res_ln_ok), never from M
@@ -1120,6 +1171,7 @@ int forward_body(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
             ffn_in = dt == F32 ? (const void*)x1 : (const void*)xT;
         }
         {   // fc1 + bias + GELU
+        if (dbg_stop == 33 && l == 0) return 0;  // (behind LayerNorm 1 / 2)
             GemmParams g{};
             g.A = ffn_in;
             g.lda = D;
@@ -1136,6 +1188,7 @@ int forward_body(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
             Prof pr(e, st, "gemm:fc1", 2.0 * gM * F * D, (gM * D + (double)F * D + gM * F) * es);
             HIP_TRY(launch_gemm(dt, wsplit_of(e, g), st));
         }
+        if (dbg_stop == 34 && l == 0) return 0;  // (behind fc1)
         // fc2 + bias + residual.  pre-LN: the result IS the residual stream after the layer (a state for l < NL-1, and
         // for the fairseq_layers / DistilHuBERT selections); post-LN: it feeds final_layer_norm.
         const int si_next = si_stream(l);

@@ -67,6 +67,14 @@ struct Tuning {
                            // epilogue rebuilds the fp32 rows it adds (bit-identical to 0 = LayerNorm 1 writes them)
     int gn_lag_one_block = 1;  // frontend.hip: 1 = GroupNorm lag sums from ONE workgroup per (4096-frame chunk, utterance) over an LDS-staged
                            // window (bit-identical to the k0-workgroups form, 95.7 -> see profiles/r06b_gn_stats.md), 0 = the earlier kernel
+    int forward_chain = 1; // engine.hip: 1 = a forward of a 16-bit / split-precision handle waits (hipStreamWaitEvent, no host wait) for the previous
+                           // such forward of ANY handle on the same device, whatever stream that one ran on.  With one handle on one stream the
+                           // wait is already implied by stream order.  Why: forwards of SEVERAL handles running at once on >= 4 streams are NOT
+                           // bit-stable in the modes whose GEMMs stage through global_load_lds (bf16 / fp16 at four streams, fp16x2 / fp32x3 at
+                           // eight; never exact fp32, which is left free to overlap): rare rows come out a few 16-bit ulps off
+                           // (tools/two_stream_probe.py, profiles/r06c_concurrent_forwards.md; no kernel or pair of kernels reproduces it in
+                           // isolation, two streams never do).  Price: sub-batches that under-fill the chip no longer overlap (four
+                           // 8-utterance forwards: 8.5 -> 12.1 ms; the same 32 utterances as ONE batch: 6.8 ms).  0 = forwards may overlap
     int comm_self_p2p = 0; // comm.hip, S3ENC_EXCHANGE_DIRECT: 1 = a rank's OWN block also travels as an ncclSend-to-self / ncclRecv-from-self
                            // pair inside the state's group instead of a device copy — on a one-GPU box this is the only way the
                            // all-pairs code (symbols, counts, datatype, group bracketing, stream order behind the layer events)

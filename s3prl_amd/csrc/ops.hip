@@ -24,7 +24,7 @@ int tuning_set(Tuning& t, const char* key, int value, const char** err) {
         {"comm_self_p2p", &Tuning::comm_self_p2p, 0, 1},     {"attn_persist", &Tuning::attn_persist, 0, 1},
         {"fp16x2_conv1_f32", &Tuning::fp16x2_conv1_f32, 0, 1}, {"gn_lag_one_block", &Tuning::gn_lag_one_block, 0, 1},
         {"ln_rows", &Tuning::ln_rows, 1, 2},                 {"ln1_fold", &Tuning::ln1_fold, 0, 1},
-        {"ln_preload", &Tuning::ln_preload, 0, 1},
+        {"ln_preload", &Tuning::ln_preload, 0, 1},           {"forward_chain", &Tuning::forward_chain, 0, 1},
     };
     static thread_local char msg[160];
     if (!key) {

@@ -307,6 +307,55 @@ def test_one_utterance_alone_equals_its_rows_in_a_batch_bit_for_bit(dtype):
     enc.close()
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+def test_forwards_of_four_handles_on_four_streams_keep_their_bits(dtype):
+    """Round 6: forwards of several handles enqueued at once on four streams (a serving process with one encoder per model, or one per
+    worker thread) must give every utterance the bits it gets alone.  Without the forward chain (tuning key `forward_chain`, default 1:
+    a forward waits on the device for the previous forward of any handle) the 16-bit modes were measured NOT bit-stable in this
+    situation — rare rows a few 16-bit ulps off, tools/two_stream_probe.py, profiles/r06c_concurrent_forwards.md — and 28 % slower."""
+    import ctypes as C
+
+    import torch
+    from s3prl_amd import _lib
+    from s3prl_amd.synth import named_config, synth_weights
+
+    cfg = named_config("hubert_base")
+    weights = synth_weights(cfg, 0)
+    S, per, n = 4, 8, 160000
+    encs = [_encoder(cfg, weights, dtype=dtype) for _ in range(S)]
+    gen = torch.Generator(device="cuda").manual_seed(77)
+    wavs = [torch.randn(n, device="cuda", generator=gen) for _ in range(S * per)]
+    lib = _lib.load()
+    T, D, NS = encs[0].num_output_frames(n), encs[0].embed_dim, encs[0].num_states()
+    streams = [torch.cuda.Stream() for _ in range(S)]
+    torch.cuda.synchronize()
+
+    def run(out, concurrent):
+        keep = []
+        for s, enc in enumerate(encs):
+            sub = wavs[s * per:(s + 1) * per]
+            ptrs = (C.c_void_p * per)(*[w.data_ptr() for w in sub])
+            lens = (C.c_int64 * per)(*[n] * per)
+            opts = _lib.S3ForwardOpts(_lib.SELECTIONS[None], _lib.F32, 0, 0, None)
+            st = streams[s if concurrent else 0]
+            _lib.check(lib.s3enc_forward_ex(enc._h, ptrs, lens, per, n, C.byref(opts), C.c_void_p(out.data_ptr() + s * per * T * D * 4),
+                                            S * per * T * D, C.c_void_p(st.cuda_stream)), "s3enc_forward_ex")
+            keep.append((ptrs, lens))
+        return keep
+
+    ref = torch.empty((NS, S * per, T, D), device="cuda")
+    k0 = run(ref, False)
+    torch.cuda.synchronize()
+    assert torch.isfinite(ref).all()
+    for trial in range(3):
+        out = torch.empty_like(ref)
+        k1 = [run(out, True) for _ in range(3)]  # three forwards per handle back to back: the streams' phases mix
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref), f"{dtype}: trial {trial}: forwards of four handles on four streams differ from the same forwards one at a time"
+    for e in encs:
+        e.close()
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16", "fp16x2"])
 def test_race_screen_repeated_runs_are_bit_identical(dtype):
     """The GEMM kernels overlap LDS-DMA (issued from inline asm, hand-counted vmcnt) with the MFMA loop; a missing wait
