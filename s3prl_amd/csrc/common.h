@@ -1,5 +1,10 @@
 // common.h — shared device helpers for the gfx950 kernels of libs3enc.
 #pragma once
+// cache-policy modifier of every global_load_lds (LDS-DMA) instruction of the 16-bit GEMM kernels: "" (default) = wave scope,
+// " sc1" = agent scope (an experiment of round 6's third session, profiles/r06c_concurrent_forwards.md; make EXTRA='-DS3_GLDS_MOD="\" sc1\""')
+#ifndef S3_GLDS_MOD
+#define S3_GLDS_MOD ""
+#endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

@@ -237,7 +237,7 @@ __global__ __launch_bounds__(128 * WN, WPE) void gemm16_big_kernel(GemmParams p)
     auto glds4 = [&](const char* gsrc, unsigned lds_dst) {  // 4 bytes per lane (the MX scales)
         unsigned keep;
         asm volatile(
-            "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+            "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" S3_GLDS_MOD "\n\ts_mov_b32 m0, %0"
             : "=&s"(keep)
             : "v"(gsrc), "s"(lds_dst)
             : "memory");
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(128 * WN, WPE) void gemm16_big_kernel(GemmParams p)
     auto glds16 = [&](const char* gsrc, unsigned lds_dst) {
         unsigned keep;
         asm volatile(
-            "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+            "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" S3_GLDS_MOD "\n\ts_mov_b32 m0, %0"
             : "=&s"(keep)
             : "v"(gsrc), "s"(lds_dst)
             : "memory");

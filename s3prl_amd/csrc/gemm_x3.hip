@@ -84,7 +84,7 @@ __global__ __launch_bounds__(512, 2) void gemm_x3_kernel(GemmParams p) {
     auto dma = [&](const char* gsrc, unsigned dst) {
         unsigned keep;
         asm volatile(
-            "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+            "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" S3_GLDS_MOD "\n\ts_mov_b32 m0, %0"
             : "=&s"(keep)
             : "v"(gsrc), "s"(dst)
             : "memory");
