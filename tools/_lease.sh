@@ -1,15 +1,9 @@
 set -u
+mkdir -p gpurun_out/r06
 export TMPDIR=/tmp
-cnt() { grep "concurrent\|second run" | python -c "
-import sys, json
-print([json.loads(l)['differing (layer, utterance) pairs'] for l in sys.stdin])"; }
-cp s3prl_amd/libs3enc.so /tmp/base.so
-for v in base sc1 sys base sc1; do
-  if [ $v = base ]; then cp /tmp/base.so s3prl_amd/libs3enc.so; else cp gpurun_variants/libs3enc_$v.so s3prl_amd/libs3enc.so; fi
-  echo "== $v bf16 (chain off)"; timeout 600 python tools/two_stream_probe.py --dtype bf16 --splits 1 4 8 --steps 5 --diagnose --tune forward_chain=0 2>&1 | cnt
-done
-for v in base sc1; do
-  if [ $v = base ]; then cp /tmp/base.so s3prl_amd/libs3enc.so; else cp gpurun_variants/libs3enc_$v.so s3prl_amd/libs3enc.so; fi
-  python bench.py --no-cpu-baseline --no-other-modes --no-parity --dtype bf16 --steps 300 --warmup 5 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print('$v bf16', d['ms_per_step'], d['clock_ghz'])"
-done
-cp /tmp/base.so s3prl_amd/libs3enc.so
+( time python -m pytest tests -m gpu -q -x > gpurun_out/r06/gputests_full_raw.log 2>&1 ) 2> gpurun_out/r06/gputests_time.log
+{ grep -E "passed|failed|error" gpurun_out/r06/gputests_full_raw.log | tail -3; cat gpurun_out/r06/gputests_time.log; } > gpurun_out/r06/gputests_final.log
+cat gpurun_out/r06/gputests_final.log
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+python bench.py > gpurun_out/r06/bench_default_final.json 2> gpurun_out/r06/bench_default_final.err
+cut -c1-400 gpurun_out/r06/bench_default_final.json
