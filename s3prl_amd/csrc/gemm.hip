@@ -330,16 +330,6 @@ hipError_t gemm_variant(const GemmParams& p, dim3 grid, hipStream_t stream, bool
 
 hipError_t launch_gemm(int dtype, const GemmParams& p0, hipStream_t stream) {
     GemmParams p = p0;
-    {   // (diagnostic, third session of round 6: S3ENC_DEBUG_EVFENCE = 1 puts an event record + a wait for it on the SAME stream in front of
-        //  every GEMM — a barrier packet with a signal instead of the queue's implicit order)
-        static const int evf = getenv("S3ENC_DEBUG_EVFENCE") ? atoi(getenv("S3ENC_DEBUG_EVFENCE")) : 0;
-        if (evf) {
-            static thread_local hipEvent_t ev = nullptr;
-            if (!ev) (void)hipEventCreateWithFlags(&ev, evf == 2 ? hipEventDefault : hipEventDisableTiming);
-            (void)hipEventRecord(ev, stream);
-            (void)hipStreamWaitEvent(stream, ev, 0);
-        }
-    }
     if (p.variant < 0) p.variant = tuning().gemm_variant;  // default 3: 64-byte stages + LDS-DMA (register staging for a ragged K)
     if (p.M <= 0 || p.N <= 0 || p.batches <= 0) return hipSuccess;
     if (dtype == F32 && p.act == 1 && tuning().gelu32 == 1) p.act = 2;  // fp32 products, the one-transcendental GELU
