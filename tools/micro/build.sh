@@ -15,4 +15,6 @@ $H tools/micro/mfma_peak.hip -o tools/micro/mfma_peak
 $H tools/micro/mx_probe.hip -o tools/micro/mx_probe
 $H tools/micro/mx_gemm_lab.hip -o tools/micro/mx_gemm_lab
 hipcc -O2 --offload-arch=gfx950 tools/micro/gemm32_lab.cpp -Iinclude -Ls3prl_amd -ls3enc -Wl,-rpath,'$ORIGIN/../../s3prl_amd' -o tools/micro/gemm32_lab
+hipcc -O2 --offload-arch=gfx950 -shared -fPIC tools/micro/lds_occupy.hip -o tools/micro/liblds_occupy.so    # tools/lds_base_probe.py
+$H tools/micro/stream_order_probe.hip -o tools/micro/stream_order_probe
 ls -la tools/micro | grep -v "\.hip\|\.cpp\|\.sh"
