@@ -310,6 +310,12 @@ int s3enc_debug_clock_sample(uint64_t* out3_device, void* stream);
  *                   with two streams, never in S3ENC_F32, no kernel alone reproduces it (profiles/r06c_concurrent_forwards.md) — so a
  *                   serving process that keeps one encoder per model or per worker thread gets every utterance's own bits by default.
  *                   0 = such forwards may overlap (small batches then fill the chip together: four 8 x 10 s forwards 12.1 -> 8.5 ms);
+ *                   (round 6, fourth session: the differing rows originate in the first conv layer's kernel of the 16-bit modes and nowhere
+ *                   else — profiles/r06d_concurrent_forwards_exclusions.md);
+ *   "conv0_fast":   16-bit outputs of the first conv layer: 1 (default) = packed fp32 taps and the packed one-transcendental GELU, 0 = scalar taps
+ *                   and libm erff (about twice that kernel's time; results a few 16-bit ulps apart).  With 0 — and forward_chain = 0 — 32 of 32
+ *                   measured runs of four / eight overlapping forwards kept their bits; why is not understood, so this is a diagnostic
+ *                   switch and the forward chain stays the protection;
  *   "comm_self_p2p": S3ENC_EXCHANGE_DIRECT test hook: 1 = a rank's own block travels as an ncclSend-to-self / ncclRecv-from-self pair
  *                   inside the state's group instead of a device copy (how the all-pairs code executes on a one-GPU box); default 0;
  *   "fp16x2_conv1_f32": S3ENC_F16X2, read at s3enc_create: 1 = conv0 writes fp32 activations and conv1 reads them through the three-term

@@ -796,6 +796,11 @@ int forward_body(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
         gate = gated ? wb.take((size_t)B * H * T * 4) : nullptr;
         ffnbuf = (ffn_tap && (fo.featurize || fo.out_dtype != F32)) ? wb.take((size_t)M * D * 4) : nullptr;
         if (!pass) HIP_TRY(e->ws.ensure_on_stream(wb.off + 4096, st));
+        // (diagnostic, profiles/r06d_concurrent_forwards_exclusions.md: S3ENC_DEBUG_POISON=1 fills the workspace with NaN patterns in front of
+        //  every forward — every buffer is written before it is read, so a correct forward does not change; a read that overtakes its
+        //  producer shows as NaN rows instead of plausible numbers)
+        static const int dbg_poison = getenv("S3ENC_DEBUG_POISON") ? atoi(getenv("S3ENC_DEBUG_POISON")) : 0;
+        if (pass && dbg_poison) HIP_TRY(hipMemsetAsync(e->ws.p, 0xFF, wb.off, st));
     }
     e->taps.clear();
 
@@ -817,6 +822,30 @@ int forward_body(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
     auto other = [&](const float* busy) { return busy == (const float*)x32 ? (float*)xpc : (float*)x32; };
 
     WavTable wt{d_ptrs, d_lens, B, n_max};
+    // (diagnostic: S3ENC_DEBUG_KEEP=1 copies conv0 and the early conv outputs aside behind their kernel, so that a FULL forward keeps them as
+    //  taps — the workspace reuses their buffers; the copies are never freed: a debugging process)
+    static const int dbg_keep = getenv("S3ENC_DEBUG_KEEP") ? atoi(getenv("S3ENC_DEBUG_KEEP")) : 0;
+    auto keep_tap = [&](const char* name, int idx, const void* src, long elems, int tdt) -> hipError_t {
+        if (!dbg_keep) return hipSuccess;
+        static std::map<std::pair<const void*, int>, std::pair<void*, size_t>> kept;
+        static std::mutex kept_mu;
+        const size_t bytes = (size_t)elems * (tdt == F32 ? 4 : 2);
+        void* kp = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(kept_mu);
+            auto& slot = kept[{(const void*)e, idx}];
+            if (slot.second < bytes) {
+                hipError_t er = hipMalloc(&slot.first, bytes);
+                if (er != hipSuccess) return er;
+                slot.second = bytes;
+            }
+            kp = slot.first;
+        }
+        hipError_t er = hipMemcpyAsync(kp, src, bytes, hipMemcpyDeviceToDevice, st);
+        if (er != hipSuccess) return er;
+        e->taps[name] = {kp, elems, tdt};
+        return hipSuccess;
+    };
     {
         Prof pr(e, st, "wav_stats", 0, 4.0 * B * n_max);
         HIP_TRY(launch_wav_norm_stats(wt, c.normalize, d_part, d_norm, st, c.wav_norm_eps));
@@ -847,6 +876,7 @@ int forward_body(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
         HIP_TRY(launch_conv0(c0f32 ? (int)F32 : dt, p, st));
         // (diagnostic, tools/two_stream_probe.py --taps: S3ENC_DEBUG_STOP = k ends the forward behind conv(k - 1) and keeps its output as a tap)
         if (dbg_stop) e->taps["conv0"] = {actA, (long)B * L[0] * C, c0f32 ? (int)F32 : dt};
+        else HIP_TRY(keep_tap("conv0", 0, actA, (long)B * L[0] * C, c0f32 ? (int)F32 : dt));
         if (dbg_stop == 1) return 0;
     }
     // conv1..: implicit GEMM on channel-last activations.  The last one feeds LayerNorm(C) in fp32, or — without that
@@ -905,6 +935,7 @@ int forward_body(s3enc_handle e, const float* const* wav_ptrs_host, const int64_
         char tn[16];
         snprintf(tn, sizeof(tn), "conv%d", i);
         if (i >= c.n_conv - 3 || dbg_stop) e->taps[tn] = {dst, (long)B * L[i] * C, f32out ? (int)F32 : dt};  // earlier ones get overwritten
+        else HIP_TRY(keep_tap(tn, i, dst, (long)B * L[i] * C, f32out ? (int)F32 : dt));
         if (dbg_stop == 1 + i) return 0;
         cur = dst;
     }

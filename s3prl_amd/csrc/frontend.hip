@@ -429,9 +429,10 @@ hipError_t launch_conv0(int dtype, const Conv0Params& p, hipStream_t s) {
     // the kernel is specialised for the first layer every released checkpoint has: k = 10, stride <= 8, C <= 1024
     if (p.k0 != 10 || p.s0 > 8 || p.s0 < 1 || p.C > 1024 || (p.C & 3)) return hipErrorInvalidValue;
     switch (dtype) {
-        case F32: return (p.fast || tuning().gelu32 == 1) ? conv0_dispatch<float, true>(p, s) : conv0_dispatch<float, false>(p, s);
-        case BF16: return conv0_dispatch<bf16_tag, true>(p, s);
-        case F16: return conv0_dispatch<f16_tag, true>(p, s);
+        case F32: return ((p.fast ? tuning().conv0_fast : tuning().gelu32) == 1) ? conv0_dispatch<float, true>(p, s) : conv0_dispatch<float, false>(p, s);
+        // (conv0_fast = 0: the FAST = false instantiation, a diagnostic of the concurrent-forward finding — kernels.h)
+        case BF16: return tuning().conv0_fast ? conv0_dispatch<bf16_tag, true>(p, s) : conv0_dispatch<bf16_tag, false>(p, s);
+        case F16: return tuning().conv0_fast ? conv0_dispatch<f16_tag, true>(p, s) : conv0_dispatch<f16_tag, false>(p, s);
     }
     return hipErrorInvalidValue;
 }

@@ -53,6 +53,13 @@ struct Tuning {
                            // 110 vs 107 / 130 vs 121 WavLM-large (profiles/r06b_attn_lab_variants.md)
     int conv0_nt = 1;      // frontend.hip, fp32 output: 1 = non-temporal row stores (the 2 GB activation streams past the caches:
                            // 0.578 -> 0.436 ms on HuBERT-base 32 x 10 s, round 4), 0 = plain stores
+    int conv0_fast = 1;    // frontend.hip, 16-bit outputs (S3ENC_BF16 / F16 / F16X2) and the split-precision modes' fp32 output: 1 = packed fp32 taps + the packed one-transcendental GELU,
+                           // 0 = scalar taps + libm erff (the FAST = false instantiation: ~2x the kernel's time, results a few 16-bit ulps
+                           // apart).  Round 6, fourth session: the rows that differ when >= 4 handles' forwards overlap ORIGINATE in
+                           // conv0_kernel<16-bit, FAST> — single frames, lanes 48-63, the low halves of the packed outputs — and with 0
+                           // (and forward_chain = 0) 32 of 32 overlapping runs kept their bits; neither half of FAST alone, nor wait states,
+                           // nor the transcendental unit explains it (profiles/r06d_concurrent_forwards_exclusions.md).  A diagnostic
+                           // switch, not a fix: the forward chain stays the default protection
     int ws_inplace = 1;    // engine.hip, post-LN layers: 1 = LayerNorm 1 and fc2 work in place on ONE fp32 buffer (49 MB less
                            // working set per layer: fc2 -3.6 %, LayerNorm -4 % in the bf16 forward, round 4), 0 = two buffers
     int gelu32 = 1;        // S3ENC_F32: 1 = the one-transcendental GELU of every mode (common.h gelu_fast; fp32 rounding level), 0 = libm erff

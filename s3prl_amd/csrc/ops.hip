@@ -25,6 +25,7 @@ int tuning_set(Tuning& t, const char* key, int value, const char** err) {
         {"fp16x2_conv1_f32", &Tuning::fp16x2_conv1_f32, 0, 1}, {"gn_lag_one_block", &Tuning::gn_lag_one_block, 0, 1},
         {"ln_rows", &Tuning::ln_rows, 1, 2},                 {"ln1_fold", &Tuning::ln1_fold, 0, 1},
         {"ln_preload", &Tuning::ln_preload, 0, 1},           {"forward_chain", &Tuning::forward_chain, 0, 1},
+        {"conv0_fast", &Tuning::conv0_fast, 0, 1},
     };
     static thread_local char msg[160];
     if (!key) {

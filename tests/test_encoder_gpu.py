@@ -356,6 +356,40 @@ def test_forwards_of_four_handles_on_four_streams_keep_their_bits(dtype):
         e.close()
 
 
+@pytest.mark.parametrize("dtype,tol", [("bf16", 3e-2), ("fp16x2", 2e-3)])
+def test_conv0_fast_0_is_the_same_layer_at_the_modes_rounding(dtype, tol):
+    """Tuning key `conv0_fast` (round 6, fourth session): 0 runs the first conv layer of the 16-bit modes on scalar taps and libm erff —
+    the instantiation with which overlapping forwards of several handles were measured bit-stable WITHOUT the forward chain
+    (profiles/r06d_concurrent_forwards_exclusions.md).  The same layer, evaluated in a different order: every state within the mode's
+    rounding of the default kernel's, run-to-run bit-identical, and the default comes back bit for bit when the key is reset."""
+    import torch
+    from s3prl_amd import _lib
+    from s3prl_amd.synth import named_config, synth_weights
+
+    cfg = named_config("hubert_base")
+    enc = _encoder(cfg, synth_weights(cfg, 0), dtype=dtype)
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    wavs = [torch.randn(n, device="cuda", generator=gen) for n in (48000, 40000, 16000)]
+    lib = _lib.load()
+    try:
+        ref = enc.forward(wavs).clone()
+        _lib.check(lib.s3enc_set_tuning(b"conv0_fast", 0), "s3enc_set_tuning")
+        a = enc.forward(wavs).clone()
+        b = enc.forward(wavs).clone()
+    finally:
+        _lib.check(lib.s3enc_set_tuning(b"conv0_fast", 1), "s3enc_set_tuning")
+    c = enc.forward(wavs).clone()
+    torch.cuda.synchronize()
+    assert torch.isfinite(a).all()
+    assert torch.equal(a, b)
+    assert torch.equal(c, ref)
+    assert not torch.equal(a, ref), "conv0_fast = 0 did not change the kernel"
+    for l in range(ref.shape[0]):
+        rel = float((a[l] - ref[l]).norm() / ref[l].norm())
+        assert rel < tol, f"{dtype}: state {l}: conv0_fast = 0 is {rel:.2e} from the default kernel"
+    enc.close()
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16", "fp16x2"])
 def test_race_screen_repeated_runs_are_bit_identical(dtype):
     """The GEMM kernels overlap LDS-DMA (issued from inline asm, hand-counted vmcnt) with the MFMA loop; a missing wait

@@ -164,11 +164,24 @@ def main():
                             dm = (a != b_).reshape(-1, width)
                             rb, cb = dm.any(axis=1), dm.any(axis=0)
                             rel = np.abs(a - b_) / (np.abs(b_) + 1e-6)
+                            if nm == "conv0":  # what IS the wrong value?  (good, bad, the same channel's good value 2 / 1 frames before and after)
+                                W_ = width
+                                A2, B2 = a.reshape(-1, W_), b_.reshape(-1, W_)
+                                ex = []
+                                for r_ in np.nonzero(rb)[0][:6]:
+                                    for c_ in np.nonzero(dm[r_])[0][:3]:
+                                        nb = {d_: float(B2[r_ + d_, c_]) for d_ in (-4, -2, -1, 1, 2, 4) if 0 <= r_ + d_ < B2.shape[0]}
+                                        ex.append({"row": int(r_), "col": int(c_), "good": float(B2[r_, c_]), "bad": float(A2[r_, c_]), "neighbours (good)": nb,
+                                                   "cols c+1..c+3 good": [float(B2[r_, c_ + k]) for k in (1, 2, 3) if c_ + k < W_]})
+                                print(json.dumps({"conv0 examples": ex}), flush=True)
                             rep.setdefault(nm, []).append({"handle": s_, "bad": nbad, "n": int(a.size), "max abs": float(np.abs(a - b_).max()),
                                                            "median rel of bad": float(np.median(rel[a != b_])),
                                                            "rows bad": int(rb.sum()), "rows": int(rb.size), "cols bad": int(cb.sum()), "cols": int(cb.size),
                                                            "bad per bad row (median)": float(np.median(dm[rb].sum(axis=1))),
-                                                           "first bad rows": [int(x) for x in np.nonzero(rb)[0][:12]]})
+                                                           "first bad rows": [int(x) for x in np.nonzero(rb)[0][:12]],
+                                                           # (row, bad columns, first, last): an ORIGIN row of a GEMM is bad inside one column tile
+                                                           "column span of bad rows": [(int(r), int(dm[r].sum()), int(np.nonzero(dm[r])[0][0]), int(np.nonzero(dm[r])[0][-1]))
+                                                                                       for r in np.nonzero(rb)[0][:16]]})
                 print(json.dumps({"splits": S, "trial": trial, "taps that differ (handle, n_bad, n, first, last, max abs)": rep,
                                   "output differs": not bool(torch.equal(o1, o2))}), flush=True)
 
@@ -190,7 +203,8 @@ def diagnose(run, ref, S, B, torch, gather=None):
                     d = (ref[l, b] - out[l, b]).abs()
                     rows = (d.amax(dim=1) > 0).nonzero().flatten()
                     bad.append((l, b, float(d.max()), int(rows.numel()), int(rows[0]), int(rows[-1])))
-        print(json.dumps({"splits": S, "how": label, "differing (layer, utterance) pairs": len(bad),
+        nan_pairs = int(torch.isnan(out).flatten(2).any(dim=2).sum().item())  # (S3ENC_DEBUG_POISON=1: a read that overtook its producer)
+        print(json.dumps({"splits": S, "how": label, "differing (layer, utterance) pairs": len(bad), "pairs with NaN": nan_pairs,
                           "first": bad[:6], "layers": sorted({x[0] for x in bad})[:14], "utterances": sorted({x[1] for x in bad})}), flush=True)
 
 
