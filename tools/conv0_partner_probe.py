@@ -80,9 +80,20 @@ def main():
                      "w2": rn(D, F, sc=0.5 * F ** -0.5).to(tdt), "bf2": rn(D, sc=0.1), "xa": rn(M, D), "xb": torch.zeros((M, D), device=dev),
                      "xT": rn(M, D).to(tdt), "qkv": rn(M, 3 * D).to(tdt), "att": z16(D), "h": rn(M, F, sc=0.3).to(tdt)})
 
+    tm = {k: [(torch.randn(sz, sz, device=dev).to(tdt), torch.randn(sz, sz, device=dev).to(tdt)) for _ in range(S)] for k, sz in (("torch_mm16_4096", 4096), ("torch_mm16_1024", 1024))}
+    tm32 = [(torch.randn(2048, 2048, device=dev), torch.randn(2048, 2048, device=dev)) for _ in range(S)]
+
     def partner(kind, s):
         j, sp = jobs[s], C.c_void_p(streams[s].cuda_stream)
         ck = _lib.check
+        if kind in tm:  # a caller's own 16-bit matrix kernels (rocBLAS / hipBLASLt through torch) on another stream
+            with torch.cuda.stream(streams[s]):
+                torch.mm(*tm[kind][s])
+            return
+        if kind == "torch_mm32":
+            with torch.cuda.stream(streams[s]):
+                torch.mm(*tm32[s])
+            return
         if kind in ("ln", "all"):
             ck(lib.s3enc_op_layernorm(DT, ptr(j["x0"]), ptr(j["g1"]), ptr(j["b1"]), M, D, 0, None, ptr(j["xT"]), sp), "ln")
         if kind in ("qkv", "all"):
