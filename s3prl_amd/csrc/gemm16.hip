@@ -144,6 +144,12 @@ __global__ __launch_bounds__(128 * WN, WPE) void gemm16_big_kernel(GemmParams p)
     const int wr_s = __builtin_amdgcn_readfirstlane(wr);  // (scalar: PP branches on it per fragment step)
     const int half = lane >> 5;
     const int l31 = lane & 31;
+    // Round 6, fourth session (profiles/r06d_concurrent_forwards_exclusions.md): a wave of ANOTHER kernel that shares a SIMD with waves issuing
+    // v_mfma_f32_32x32x16_{bf16,f16} was measured to compute single VALU results wrong (conv0_kernel beside these kernels' 182 / 198 / 218-register
+    // instantiations: 4 of 4 trials; beside the 256-register ones, which leave no room, or beside the same GEMM on two 32x32x8 MFMAs: never).
+    // The two-waves-per-SIMD instantiations therefore claim the whole register file (v255 reserved -> 256 allocated; their occupancy is two
+    // waves either way): no foreign wave — this library's or a caller's — can be placed beside them.
+    if constexpr (WPE == 2) asm volatile("" ::: "v255");
 
     // XCD-aware tile order (see gemm.hip): every XCD gets a contiguous range of (batch, m-tile, n-tile), n fastest
     const int n_tiles = (p.N + BN - 1) / BN;

@@ -37,6 +37,7 @@ __device__ __forceinline__ f32x16 mma_bf16(const uint4& a, const uint4& b, f32x1
 
 template <int WTM>
 __global__ __launch_bounds__(512, 2) void gemm_x3_kernel(GemmParams p) {
+    asm volatile("" ::: "v255");  // the whole register file of the SIMD: no foreign wave beside these 16-bit MFMAs (see gemm16.hip)
     constexpr int BM = 2 * WTM, MI = WTM / 32;
     constexpr int A_BYTES = BM * XROWB, B_BYTES = XBN * XROWB, STAGE_BYTES = A_BYTES + B_BYTES;
     constexpr int NLA = BM / 64, NLB = XBN / 64, NL = NLA + NLB;  // LDS-DMA pieces per wave per stage
