@@ -308,7 +308,8 @@ int s3enc_debug_clock_sample(uint64_t* out3_device, void* stream);
  *                   device; no host wait; with one handle on one stream it adds nothing to stream order).  Forwards of several handles
  *                   overlapping on four or more streams were measured NOT bit-stable in those modes — rare rows a few 16-bit ulps off, never
  *                   with two streams, never in S3ENC_F32 (profiles/r06c_concurrent_forwards.md; round 6's fourth session traced every such row to the first
- *                   conv layer's kernel computing single frames wrong while other kernels' waves share its SIMDs — mechanism unknown, r06d) — so a
+ *                   conv layer's kernel computing single frames wrong while waves that issue the double-rate 16-bit MFMA (v_mfma_f32_32x32x16) share its SIMD —
+ *                   a cross-wave effect; the 16-bit tile-GEMM kernels therefore claim their SIMD's whole register file, r06d) — so a
  *                   serving process that keeps one encoder per model or per worker thread gets every utterance's own bits by default.
  *                   0 = such forwards may overlap (small batches then fill the chip together: four 8 x 10 s forwards 12.1 -> 8.5 ms);
  *                   (round 6, fourth session: the differing rows originate in the first conv layer's kernel of the 16-bit modes and nowhere
